@@ -1,0 +1,185 @@
+/*
+ * mi355rag.h — C-ABI of libmi355rag.so: the MI355X (gfx950) dense-retrieval hot path.
+ *
+ * This is the drop-in boundary for the ONE data-parallel path of alxd/rag's
+ * advanced_rag.py: chunk embedding + exact (flat) top-k search behind the
+ * vector-store retriever interface.  The reference has no FFI of its own (it is
+ * pure Python that calls pip packages), so every entry point cites the reference
+ * call site whose third-party arithmetic it replaces:
+ *
+ *   advanced_rag.py:104-107  HuggingFaceEmbeddings(all-MiniLM-L6-v2, cpu)  -> mi_encoder_*
+ *   advanced_rag.py:295      FAISS.from_documents(split_data, embed_func)  -> mi_index_create / mi_index_add*
+ *   advanced_rag.py:296,303  vector_store.as_retriever(k).invoke(query)    -> mi_index_search*
+ *
+ * Conventions
+ *   - every function returns MI_OK (0) or a negative mi_status; no exceptions, no aborts;
+ *     mi_last_error() returns a thread-local human-readable message for the last failure
+ *     on the calling thread.
+ *   - handles are opaque; each is freed only by its *_destroy.
+ *   - the caller owns every buffer it passes in, and every output buffer.
+ *   - one mi_ctx per GPU, one process per GPU (multi-GPU = one process per rank; the
+ *     exchange step is a torch.distributed/RCCL all-gather in the host layer followed by
+ *     mi_topk_merge_dev).  Every entry point selects its ctx's device itself
+ *     (hipSetDevice) and takes the handle's mutex, so it may be called from arbitrary
+ *     host threads (LangChain RunnableParallel workers, Gradio handlers).
+ *   - "*_dev" variants take raw device pointers (e.g. torch.Tensor.data_ptr()) and a
+ *     hipStream_t passed as void* (NULL = the ctx's own stream); they enqueue work and
+ *     return without a host sync unless noted.  Host-pointer variants are synchronous.
+ *   - the library has NO CPU fallback: without a gfx950 device mi_init fails with
+ *     MI_ERR_NO_DEVICE.
+ *
+ * Score / order semantics (identical in oracle/oracle_search.c, the CPU restatement):
+ *   dot(q,x)   = fmaf chain over k = 0..d-1 starting from +0.0f, in fp32
+ *                (for a BF16 index both q and x are first rounded to bf16, RNE).
+ *   IP metric  : score = dot(q,x), best = largest.
+ *   L2 metric  : score = max(0, fmaf(-2, dot(q,x), dot(q,q) + dot(x,x))), best = smallest.
+ *   NaN scores rank as the worst possible value; ties rank the LOWER id first.
+ *   Results are best-first; when fewer than k rows exist the tail is id = -1 and
+ *   score = -inf (IP) / +inf (L2)  [faiss IndexFlat convention].
+ */
+#ifndef MI355RAG_H
+#define MI355RAG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi_ctx     mi_ctx;
+typedef struct mi_index   mi_index;
+typedef struct mi_encoder mi_encoder;
+
+typedef enum {
+    MI_OK               =  0,
+    MI_ERR_INVALID_ARG  = -1,
+    MI_ERR_NO_DEVICE    = -2,   /* no gfx950 GPU / HIP runtime failure at init */
+    MI_ERR_HIP          = -3,   /* a HIP call failed; see mi_last_error() */
+    MI_ERR_OOM          = -4,
+    MI_ERR_UNSUPPORTED  = -5,   /* e.g. k > MI_MAX_K */
+    MI_ERR_INTERNAL     = -6
+} mi_status;
+
+enum { MI_METRIC_IP = 0, MI_METRIC_L2 = 1 };
+enum { MI_DTYPE_F32 = 0, MI_DTYPE_BF16 = 1 };
+
+/* search path selection (mi_index_set_mode) */
+enum {
+    MI_MODE_AUTO  = 0,  /* MFMA scan + certificate where available, exact scan otherwise */
+    MI_MODE_EXACT = 1,  /* always the canonical-order fp32 scan (also the fallback path) */
+    MI_MODE_FAST  = 2   /* MFMA scan + certificate; error if the index cannot use it */
+};
+
+#define MI_MAX_K 2048
+
+/* ------------------------------------------------------------------ context */
+
+/* Opens device `device_id` (must be gfx950), creates the ctx stream.  No counterpart in
+ * the reference (it is CPU-only, advanced_rag.py:106 "device": "cpu"). */
+int  mi_init(int device_id, mi_ctx** out);
+void mi_ctx_destroy(mi_ctx* ctx);
+/* Blocks until all work enqueued on the ctx stream has finished. */
+int  mi_ctx_synchronize(mi_ctx* ctx);
+const char* mi_last_error(void);
+const char* mi_version(void);
+
+/* ------------------------------------------------------------------ flat index
+ * Replaces faiss.IndexFlatL2 / IndexFlatIP as created by FAISS.from_documents
+ * (advanced_rag.py:295; langchain-community 0.0.19 -> faiss-cpu 1.7.3, requirements.txt:3,6). */
+
+int  mi_index_create(mi_ctx* ctx, int dim, int metric, int dtype, mi_index** out);
+void mi_index_destroy(mi_index* idx);
+
+/* Optional: pre-size device storage for n_rows rows in total (avoids regrowth copies). */
+int  mi_index_reserve(mi_index* idx, int64_t n_rows);
+
+/* Appends n rows (host, fp32, row-major [n][dim]); copies, caller keeps ownership.
+ * index.add(np.array(embeddings, float32)) in the reference's FAISS wrapper. */
+int  mi_index_add(mi_index* idx, int64_t n, const float* x_host);
+/* Same from device memory; src_dtype MI_DTYPE_F32 or MI_DTYPE_BF16, row pitch = dim elements. */
+int  mi_index_add_dev(mi_index* idx, int64_t n, const void* x_dev, int src_dtype, void* stream);
+/* Appends n synthetic rows generated on device by the counter-based generator
+ * (seed, global row number = id_base + current ntotal + i); rows are L2-normalised when
+ * `normalize` != 0.  Bench/test input only. */
+int  mi_index_add_synthetic(mi_index* idx, int64_t n, uint64_t seed, int normalize);
+
+int64_t mi_index_ntotal(const mi_index* idx);
+int  mi_index_dim(const mi_index* idx);
+/* ids reported by search = id_base + local row number (row shards of one corpus). */
+int  mi_index_set_id_base(mi_index* idx, int64_t id_base);
+int  mi_index_set_mode(mi_index* idx, int mode);
+/* Removes all rows, keeps storage (reset_app_updated, advanced_rag.py:435-437). */
+int  mi_index_reset(mi_index* idx);
+
+/* Copies rows [row0, row0+n) back as fp32 (the stored values, i.e. bf16-rounded for a BF16
+ * index) — faiss reconstruct_n; used by the parity tests. */
+int  mi_index_get_rows(mi_index* idx, int64_t row0, int64_t n, float* out_host);
+
+/* Exact top-k.  index.search(np.array([v], float32), k) in the reference
+ * (advanced_rag.py:296 -> similarity_search -> faiss IndexFlat::search).
+ * q_host [nq][dim] fp32; out_scores [nq][k] fp32; out_ids [nq][k] int64 (-1 padded). */
+int  mi_index_search(mi_index* idx, int64_t nq, const float* q_host, int k,
+                     float* out_scores, int64_t* out_ids);
+/* Device-pointer variant: all three buffers in device memory.  Synchronises the stream once
+ * internally (to read the certificate-failure count) before returning. */
+int  mi_index_search_dev(mi_index* idx, int64_t nq, const float* q_dev, int k,
+                         float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+
+/* Counters since creation: out[0] queries searched, out[1] queries answered by the MFMA
+ * path with a passing certificate, out[2] queries re-run on the exact path, out[3] corpus
+ * rows scanned by the last search. */
+int  mi_index_stats(const mi_index* idx, int64_t out[4]);
+
+/* Timing of the last search's dominant scan kernel, measured with HIP events on the stream
+ * the kernel ran on: out_ms = total milliseconds, out_launches = launches it covers,
+ * out_kind = 0 exact fp32 scan, 1 bf16 MFMA scan. */
+int  mi_index_last_scan_time(const mi_index* idx, float* out_ms, int* out_launches, int* out_kind);
+
+/* Merges `nlists` best-first lists per query into one best-first list of length k
+ * (the step after the all-gather of per-GPU top-k).
+ * in_scores [nq][nlists*k_in] fp32, in_ids same shape int64 (id < 0 = padding), all device. */
+int  mi_topk_merge_dev(mi_ctx* ctx, int metric, int64_t nq, int nlists, int k_in,
+                       const float* in_scores_dev, const int64_t* in_ids_dev,
+                       int k, float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+
+/* ------------------------------------------------------------------ encoder
+ * Replaces HuggingFaceEmbeddings(...).embed_documents / embed_query
+ * (advanced_rag.py:104-107; sentence-transformers -> transformers BertModel,
+ * modeling_bert.py) from token ids onward: embeddings + LN, L x [QKV, softmax(QK^T/sqrt(dh)
+ * + mask) V, out-proj + residual + LN, FFN1 + erf-GELU, FFN2 + residual + LN],
+ * masked mean-pool, L2-normalise. */
+
+typedef struct {
+    int32_t vocab_size;               /* 30522 */
+    int32_t hidden_size;              /* 384; must be a multiple of 128 and <= 1024 */
+    int32_t num_hidden_layers;        /* 6 */
+    int32_t num_attention_heads;      /* 12; head size must be 32 or 64 */
+    int32_t intermediate_size;        /* 1536; multiple of 128 */
+    int32_t max_position_embeddings;  /* 512 */
+    int32_t type_vocab_size;          /* 2 */
+    float   layer_norm_eps;           /* 1e-12 */
+    int32_t normalize;                /* 1 = L2-normalise the pooled vector */
+} mi_bert_config;
+
+/* Number of fp32 elements mi_encoder_create expects in weights_blob for cfg (layout in
+ * DESIGN.md "encoder weights blob"; rag_amd/encoder_weights.py packs it from a
+ * safetensors / state_dict with the HuggingFace BERT parameter names). */
+int64_t mi_encoder_blob_elems(const mi_bert_config* cfg);
+
+int  mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg,
+                       const float* weights_blob_host, size_t n_elems, mi_encoder** out);
+void mi_encoder_destroy(mi_encoder* enc);
+
+/* ids, mask: host int32 [B][L] (mask 1 = token, 0 = padding); out_emb host fp32 [B][hidden]. */
+int  mi_encoder_encode(mi_encoder* enc, int64_t B, int L, const int32_t* ids,
+                       const int32_t* mask, float* out_emb);
+int  mi_encoder_encode_dev(mi_encoder* enc, int64_t B, int L, const int32_t* ids_dev,
+                           const int32_t* mask_dev, float* out_emb_dev, void* stream);
+/* Timing of the last encode (all kernels), HIP events on its stream. */
+int  mi_encoder_last_time(const mi_encoder* enc, float* out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355RAG_H */

@@ -1,0 +1,533 @@
+// capi.hip — the extern "C" boundary of libmi355rag.so (include/mi355rag.h): contexts, the
+// flat index (FAISS.from_documents / as_retriever, advanced_rag.py:295-296) and the search
+// orchestration: MFMA scan + certificate where available, canonical exact scan otherwise.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include <new>
+#include <vector>
+#include "kernels.h"
+
+// ---------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+void mi_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* mi_last_error(void) { return g_err; }
+extern "C" const char* mi_version(void) { return "mi355rag 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------- objects
+struct mi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+};
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return MI_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = (bytes + 255) / 256 * 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; mi_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return MI_ERR_OOM; }
+        cap = want;
+        return MI_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct mi_index {
+    mi_ctx* ctx = nullptr;
+    int d = 0, d_pad = 0, metric = 0, dtype = 0, mode = MI_MODE_AUTO;
+    int64_t n = 0, cap_rows = 0, id_base = 0;
+    void* rows = nullptr;       // [cap_rows][d_pad] fp32 or bf16
+    float* xx = nullptr;        // [cap_rows] canonical squared norms
+    float* max_xx = nullptr;    // device scalar: max over rows of xx
+    std::mutex mu;
+    // search workspace (grow-only)
+    DevBuf q_in, q_canon, q_bf16, qq, dense, pair_s, pair_i, lists, cnts, thrs, fail, sub_q, sub_qq, sub_s, sub_i, out_s, out_i;
+    // stats
+    int64_t st_queries = 0, st_fast = 0, st_exact = 0, st_rows = 0;
+    // scan timing of the last search
+    std::vector<hipEvent_t> ev_pool;
+    int ev_used = 0;
+    int last_kind = 0;
+    float last_ms = 0.0f;
+    int last_launches = 0;
+    size_t elem() const { return dtype == MI_DTYPE_F32 ? 4 : 2; }
+};
+
+struct DeviceGuard {
+    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); want = dev; }
+    ~DeviceGuard() { if (prev != want && prev >= 0) (void)hipSetDevice(prev); }
+    int prev = -1, want = -1;
+};
+
+// ---------------------------------------------------------------- context
+extern "C" int mi_init(int device_id, mi_ctx** out)
+{
+    if (!out) { mi_set_error("mi_init: out is NULL"); return MI_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        mi_set_error("mi_init: no HIP device visible (this library has no CPU fallback)");
+        return MI_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= ndev) { mi_set_error("mi_init: device %d out of range [0,%d)", device_id, ndev); return MI_ERR_INVALID_ARG; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { mi_set_error("mi_init: hipGetDeviceProperties failed"); return MI_ERR_NO_DEVICE; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        mi_set_error("mi_init: device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+        return MI_ERR_NO_DEVICE;
+    }
+    DeviceGuard g(device_id);
+    mi_ctx* c = new (std::nothrow) mi_ctx();
+    if (!c) { mi_set_error("mi_init: out of host memory"); return MI_ERR_OOM; }
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; mi_set_error("mi_init: hipStreamCreate failed: %s", hipGetErrorString(e)); return MI_ERR_HIP; }
+    *out = c;
+    return MI_OK;
+}
+
+extern "C" void mi_ctx_destroy(mi_ctx* ctx)
+{
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int mi_ctx_synchronize(mi_ctx* ctx)
+{
+    MI_REQUIRE(ctx, "mi_ctx_synchronize: ctx is NULL");
+    DeviceGuard g(ctx->device);
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- index: storage
+extern "C" int mi_index_create(mi_ctx* ctx, int dim, int metric, int dtype, mi_index** out)
+{
+    MI_REQUIRE(ctx && out, "mi_index_create: NULL argument");
+    *out = nullptr;
+    MI_REQUIRE(dim > 0 && dim <= 65536, "mi_index_create: dim %d out of range", dim);
+    MI_REQUIRE(metric == MI_METRIC_IP || metric == MI_METRIC_L2, "mi_index_create: unknown metric %d", metric);
+    MI_REQUIRE(dtype == MI_DTYPE_F32 || dtype == MI_DTYPE_BF16, "mi_index_create: unknown dtype %d", dtype);
+    DeviceGuard g(ctx->device);
+    mi_index* x = new (std::nothrow) mi_index();
+    if (!x) { mi_set_error("mi_index_create: out of host memory"); return MI_ERR_OOM; }
+    x->ctx = ctx; x->d = dim; x->metric = metric; x->dtype = dtype;
+    x->d_pad = mi_pad_dim(dim);
+    // the MFMA scan is built for 128 / 384 / 768-element rows: pad a BF16 index up to the next one
+    if (dtype == MI_DTYPE_BF16) {
+        if (x->d_pad > 128 && x->d_pad < 384) x->d_pad = 384;
+        else if (x->d_pad > 384 && x->d_pad < 768) x->d_pad = 768;
+    }
+    hipError_t e = hipMalloc((void**)&x->max_xx, 256);
+    if (e != hipSuccess) { delete x; mi_set_error("mi_index_create: hipMalloc failed: %s", hipGetErrorString(e)); return MI_ERR_OOM; }
+    e = hipMemsetAsync(x->max_xx, 0, 256, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(x->max_xx); delete x; mi_set_error("mi_index_create: memset failed"); return MI_ERR_HIP; }
+    *out = x;
+    return MI_OK;
+}
+
+extern "C" void mi_index_destroy(mi_index* idx)
+{
+    if (!idx) return;
+    DeviceGuard g(idx->ctx->device);
+    (void)hipStreamSynchronize(idx->ctx->stream);
+    if (idx->rows) (void)hipFree(idx->rows);
+    if (idx->xx) (void)hipFree(idx->xx);
+    if (idx->max_xx) (void)hipFree(idx->max_xx);
+    DevBuf* bufs[] = {&idx->q_in, &idx->q_canon, &idx->q_bf16, &idx->qq, &idx->dense, &idx->pair_s, &idx->pair_i,
+                      &idx->lists, &idx->cnts, &idx->thrs, &idx->fail, &idx->sub_q, &idx->sub_qq, &idx->sub_s,
+                      &idx->sub_i, &idx->out_s, &idx->out_i};
+    for (DevBuf* b : bufs) b->release();
+    for (hipEvent_t ev : idx->ev_pool) (void)hipEventDestroy(ev);
+    delete idx;
+}
+
+static int index_reserve_locked(mi_index* x, int64_t rows_total)
+{
+    if (rows_total <= x->cap_rows) return MI_OK;
+    if (rows_total >= ((int64_t)1 << 32)) { mi_set_error("index: more than 2^32-1 rows per shard is not supported"); return MI_ERR_UNSUPPORTED; }
+    hipStream_t st = x->ctx->stream;
+    void* nrows = nullptr;
+    float* nxx = nullptr;
+    const size_t row_bytes = (size_t)x->d_pad * x->elem();
+    hipError_t e = hipMalloc(&nrows, (size_t)rows_total * row_bytes);
+    if (e != hipSuccess) { mi_set_error("index: hipMalloc(%zu) for rows failed: %s", (size_t)rows_total * row_bytes, hipGetErrorString(e)); return MI_ERR_OOM; }
+    e = hipMalloc((void**)&nxx, (size_t)rows_total * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(nrows); mi_set_error("index: hipMalloc for norms failed: %s", hipGetErrorString(e)); return MI_ERR_OOM; }
+    if (x->n > 0) {
+        MI_HIP(hipMemcpyAsync(nrows, x->rows, (size_t)x->n * row_bytes, hipMemcpyDeviceToDevice, st));
+        MI_HIP(hipMemcpyAsync(nxx, x->xx, (size_t)x->n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    MI_HIP(hipStreamSynchronize(st));
+    if (x->rows) (void)hipFree(x->rows);
+    if (x->xx) (void)hipFree(x->xx);
+    x->rows = nrows; x->xx = nxx; x->cap_rows = rows_total;
+    return MI_OK;
+}
+
+extern "C" int mi_index_reserve(mi_index* idx, int64_t n_rows)
+{
+    MI_REQUIRE(idx && n_rows >= 0, "mi_index_reserve: bad argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    DeviceGuard g(idx->ctx->device);
+    return index_reserve_locked(idx, n_rows);
+}
+
+static int grow_for(mi_index* x, int64_t add)
+{
+    const int64_t need = x->n + add;
+    if (need <= x->cap_rows) return MI_OK;
+    int64_t cap = x->cap_rows > 0 ? x->cap_rows + x->cap_rows / 2 : 1024;
+    if (cap < need) cap = need;
+    return index_reserve_locked(x, cap);
+}
+
+static inline void* row_ptr(mi_index* x, int64_t r) { return (char*)x->rows + (size_t)r * x->d_pad * x->elem(); }
+
+extern "C" int mi_index_add_dev(mi_index* idx, int64_t n, const void* x_dev, int src_dtype, void* stream)
+{
+    MI_REQUIRE(idx && n >= 0 && (x_dev || n == 0), "mi_index_add_dev: bad argument");
+    MI_REQUIRE(src_dtype == MI_DTYPE_F32 || src_dtype == MI_DTYPE_BF16, "mi_index_add_dev: unknown src dtype");
+    if (n == 0) return MI_OK;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    DeviceGuard g(idx->ctx->device);
+    hipStream_t st = stream ? (hipStream_t)stream : idx->ctx->stream;
+    MI_TRY(grow_for(idx, n));
+    MI_TRY(mi_launch_ingest(st, x_dev, src_dtype, n, idx->d, idx->d_pad, idx->dtype, row_ptr(idx, idx->n)));
+    MI_TRY(mi_launch_row_norms(st, row_ptr(idx, idx->n), idx->dtype, n, idx->d_pad, idx->xx + idx->n, idx->max_xx));
+    idx->n += n;
+    return MI_OK;
+}
+
+extern "C" int mi_index_add(mi_index* idx, int64_t n, const float* x_host)
+{
+    MI_REQUIRE(idx && n >= 0 && (x_host || n == 0), "mi_index_add: bad argument");
+    if (n == 0) return MI_OK;
+    DeviceGuard g(idx->ctx->device);
+    hipStream_t st = idx->ctx->stream;
+    // stage through a device buffer in slabs (bounded extra memory for huge adds)
+    const int64_t slab = (int64_t)((256ull << 20) / ((size_t)idx->d * 4)) > 0 ? (int64_t)((256ull << 20) / ((size_t)idx->d * 4)) : 1;
+    void* stage = nullptr;
+    const int64_t first = n < slab ? n : slab;
+    MI_HIP(hipMalloc(&stage, (size_t)first * idx->d * 4));
+    int rc = MI_OK;
+    for (int64_t off = 0; off < n && rc == MI_OK; off += slab) {
+        const int64_t m = (n - off < slab) ? n - off : slab;
+        hipError_t e = hipMemcpyAsync(stage, x_host + off * idx->d, (size_t)m * idx->d * 4, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { mi_set_error("mi_index_add: H2D copy failed: %s", hipGetErrorString(e)); rc = MI_ERR_HIP; break; }
+        rc = mi_index_add_dev(idx, m, stage, MI_DTYPE_F32, st);
+        if (rc == MI_OK && hipStreamSynchronize(st) != hipSuccess) { mi_set_error("mi_index_add: sync failed"); rc = MI_ERR_HIP; }
+    }
+    (void)hipFree(stage);
+    return rc;
+}
+
+extern "C" int mi_index_add_synthetic(mi_index* idx, int64_t n, uint64_t seed, int normalize)
+{
+    MI_REQUIRE(idx && n >= 0, "mi_index_add_synthetic: bad argument");
+    if (n == 0) return MI_OK;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    DeviceGuard g(idx->ctx->device);
+    hipStream_t st = idx->ctx->stream;
+    MI_TRY(grow_for(idx, n));
+    // chunked so the launch grid stays small
+    const int64_t chunk = (int64_t)1 << 24;
+    for (int64_t off = 0; off < n; off += chunk) {
+        const int64_t m = (n - off < chunk) ? n - off : chunk;
+        MI_TRY(mi_launch_synth(st, row_ptr(idx, idx->n + off), idx->dtype, m, idx->d, idx->d_pad, seed,
+                               idx->id_base + idx->n + off, normalize));
+        MI_TRY(mi_launch_row_norms(st, row_ptr(idx, idx->n + off), idx->dtype, m, idx->d_pad, idx->xx + idx->n + off, idx->max_xx));
+    }
+    MI_HIP(hipStreamSynchronize(st));      // later searches may run on a caller's stream
+    idx->n += n;
+    return MI_OK;
+}
+
+extern "C" int64_t mi_index_ntotal(const mi_index* idx) { return idx ? idx->n : -1; }
+extern "C" int mi_index_dim(const mi_index* idx) { return idx ? idx->d : -1; }
+extern "C" int mi_index_set_id_base(mi_index* idx, int64_t id_base)
+{
+    MI_REQUIRE(idx && id_base >= 0, "mi_index_set_id_base: bad argument");
+    idx->id_base = id_base;
+    return MI_OK;
+}
+extern "C" int mi_index_set_mode(mi_index* idx, int mode)
+{
+    MI_REQUIRE(idx && mode >= MI_MODE_AUTO && mode <= MI_MODE_FAST, "mi_index_set_mode: bad argument");
+    idx->mode = mode;
+    return MI_OK;
+}
+extern "C" int mi_index_reset(mi_index* idx)
+{
+    MI_REQUIRE(idx, "mi_index_reset: idx is NULL");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    DeviceGuard g(idx->ctx->device);
+    idx->n = 0;
+    MI_HIP(hipMemsetAsync(idx->max_xx, 0, 256, idx->ctx->stream));
+    MI_HIP(hipStreamSynchronize(idx->ctx->stream));
+    return MI_OK;
+}
+
+extern "C" int mi_index_get_rows(mi_index* idx, int64_t row0, int64_t n, float* out_host)
+{
+    MI_REQUIRE(idx && out_host && row0 >= 0 && n >= 0 && row0 + n <= idx->n, "mi_index_get_rows: range [%lld,%lld) outside [0,%lld)",
+               (long long)row0, (long long)(row0 + n), (long long)(idx ? idx->n : 0));
+    if (n == 0) return MI_OK;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    DeviceGuard g(idx->ctx->device);
+    hipStream_t st = idx->ctx->stream;
+    float* tmp = nullptr;
+    MI_HIP(hipMalloc((void**)&tmp, (size_t)n * idx->d * 4));
+    int rc = mi_launch_export_rows(st, row_ptr(idx, row0), idx->dtype, n, idx->d, idx->d_pad, tmp);
+    if (rc == MI_OK) {
+        hipError_t e = hipMemcpyAsync(out_host, tmp, (size_t)n * idx->d * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { mi_set_error("mi_index_get_rows: copy failed: %s", hipGetErrorString(e)); rc = MI_ERR_HIP; }
+    }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+extern "C" int mi_index_stats(const mi_index* idx, int64_t out[4])
+{
+    MI_REQUIRE(idx && out, "mi_index_stats: NULL argument");
+    out[0] = idx->st_queries; out[1] = idx->st_fast; out[2] = idx->st_exact; out[3] = idx->st_rows;
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- scan timing (HIP events on the scan's own stream)
+static int ev_begin(mi_index* x, hipStream_t st)
+{
+    if ((size_t)x->ev_used + 2 > x->ev_pool.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t ev;
+            MI_HIP(hipEventCreate(&ev));
+            x->ev_pool.push_back(ev);
+        }
+    }
+    MI_HIP(hipEventRecord(x->ev_pool[x->ev_used], st));
+    return MI_OK;
+}
+static int ev_end(mi_index* x, hipStream_t st)
+{
+    MI_HIP(hipEventRecord(x->ev_pool[x->ev_used + 1], st));
+    x->ev_used += 2;
+    return MI_OK;
+}
+
+extern "C" int mi_index_last_scan_time(const mi_index* idx, float* out_ms, int* out_launches, int* out_kind)
+{
+    MI_REQUIRE(idx, "mi_index_last_scan_time: idx is NULL");
+    mi_index* x = const_cast<mi_index*>(idx);
+    std::lock_guard<std::mutex> lk(x->mu);
+    if (x->ev_used > 0) {
+        DeviceGuard g(x->ctx->device);
+        float total = 0.0f;
+        for (int i = 0; i + 1 < x->ev_used; i += 2) {
+            MI_HIP(hipEventSynchronize(x->ev_pool[i + 1]));
+            float ms = 0.0f;
+            MI_HIP(hipEventElapsedTime(&ms, x->ev_pool[i], x->ev_pool[i + 1]));
+            total += ms;
+        }
+        x->last_ms = total;
+        x->last_launches = x->ev_used / 2;
+        x->ev_used = 0;
+    }
+    if (out_ms) *out_ms = x->last_ms;
+    if (out_launches) *out_launches = x->last_launches;
+    if (out_kind) *out_kind = x->last_kind;
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- search: exact path
+// Scores nq prepared queries (q_canon/qq, device) against all rows in dense segments and
+// leaves the best k per query at out_s/out_i (device, row stride k).
+static int exact_search(mi_index* x, hipStream_t st, const float* q_canon, const float* qq, int nq, int k,
+                        float* out_s, int64_t* out_i, bool timed)
+{
+    if (nq <= 0) return MI_OK;
+    const int64_t n = x->n;
+    if (n == 0) return mi_launch_fill_pad(st, x->metric, nq, k, out_s, out_i, k);
+    // dense workspace: up to 256M scores (1 GiB); queries in chunks of <= 4096
+    const int64_t ws_elems = (int64_t)256 << 20;
+    const int qc_max = nq < 4096 ? nq : 4096;
+    int64_t seg_rows = ws_elems / qc_max;
+    if (seg_rows > n) seg_rows = n;
+    if (seg_rows > ((int64_t)65535 * 256)) seg_rows = (int64_t)65535 * 256;
+    seg_rows = seg_rows / 256 * 256;
+    if (seg_rows < 256) seg_rows = 256;
+    MI_TRY(x->dense.ensure((size_t)qc_max * seg_rows * sizeof(float)));
+    const bool multi = n > seg_rows;
+    if (multi) {
+        MI_TRY(x->pair_s.ensure((size_t)qc_max * 2 * k * sizeof(float)));
+        MI_TRY(x->pair_i.ensure((size_t)qc_max * 2 * k * sizeof(int64_t)));
+    }
+    float* S = x->dense.as<float>();
+    for (int q0 = 0; q0 < nq; q0 += qc_max) {
+        const int qc = (nq - q0 < qc_max) ? nq - q0 : qc_max;
+        float* os = out_s + (int64_t)q0 * k;
+        int64_t* oi = out_i + (int64_t)q0 * k;
+        if (multi) MI_TRY(mi_launch_fill_pad(st, x->metric, qc, k, x->pair_s.as<float>(), x->pair_i.as<int64_t>(), 2 * k));
+        for (int64_t r0 = 0; r0 < n; r0 += seg_rows) {
+            const int nr = (int)((n - r0 < seg_rows) ? n - r0 : seg_rows);
+            if (timed) MI_TRY(ev_begin(x, st));
+            MI_TRY(mi_launch_scan_dense(st, x->rows, x->dtype, r0, nr, x->d_pad, q_canon + (int64_t)q0 * x->d_pad, qc, S, seg_rows));
+            if (timed) MI_TRY(ev_end(x, st));
+            if (!multi) {
+                MI_TRY(mi_launch_select_dense(st, S, seg_rows, nr, x->xx + r0, qq + q0, x->metric, qc, k, x->id_base + r0, os, oi, k));
+            } else {
+                MI_TRY(mi_launch_select_dense(st, S, seg_rows, nr, x->xx + r0, qq + q0, x->metric, qc, k, x->id_base + r0,
+                                              x->pair_s.as<float>() + k, x->pair_i.as<int64_t>() + k, 2 * k));
+                const bool last = r0 + seg_rows >= n;
+                if (!last) MI_TRY(mi_launch_merge(st, x->metric, qc, 2 * k, x->pair_s.as<float>(), x->pair_i.as<int64_t>(), 2 * k, k,
+                                                  x->pair_s.as<float>(), x->pair_i.as<int64_t>(), 2 * k));
+                else MI_TRY(mi_launch_merge(st, x->metric, qc, 2 * k, x->pair_s.as<float>(), x->pair_i.as<int64_t>(), 2 * k, k, os, oi, k));
+            }
+        }
+    }
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- search: orchestration
+static int search_dev_locked(mi_index* x, int64_t nq64, const float* q_dev, int k, float* out_s, int64_t* out_i, hipStream_t st)
+{
+    MI_REQUIRE(nq64 >= 0 && nq64 < ((int64_t)1 << 24), "search: nq %lld out of range", (long long)nq64);
+    MI_REQUIRE(k >= 1, "search: k must be >= 1");
+    if (k > MI_MAX_K) { mi_set_error("search: k=%d exceeds MI_MAX_K=%d", k, MI_MAX_K); return MI_ERR_UNSUPPORTED; }
+    const int nq = (int)nq64;
+    if (nq == 0) return MI_OK;
+    const int64_t n = x->n;
+    x->ev_used = 0;
+
+    bool fast = false;
+    mi_mfma_plan plan{};
+    if (x->mode != MI_MODE_EXACT && x->dtype == MI_DTYPE_BF16 && x->metric == MI_METRIC_IP &&
+        mi_mfma_supported(x->d_pad, k) && mi_mfma_make_plan(n, x->d_pad, nq, k, &plan) == MI_OK)
+        fast = true;
+    if (x->mode == MI_MODE_FAST && !fast) {
+        mi_set_error("search: MI_MODE_FAST requested but the MFMA path does not cover this index (dtype=%d metric=%d d_pad=%d n=%lld k=%d)",
+                     x->dtype, x->metric, x->d_pad, (long long)n, k);
+        return MI_ERR_UNSUPPORTED;
+    }
+
+    const int nq_alloc = fast ? plan.nq_pad : nq;
+    MI_TRY(x->q_canon.ensure((size_t)nq_alloc * x->d_pad * sizeof(float)));
+    MI_TRY(x->qq.ensure((size_t)nq_alloc * sizeof(float)));
+    uint16_t* qb = nullptr;
+    if (fast) {
+        MI_TRY(x->q_bf16.ensure((size_t)plan.nq_pad * x->d_pad * sizeof(uint16_t)));
+        qb = x->q_bf16.as<uint16_t>();
+        if (plan.nq_pad > nq)
+            MI_HIP(hipMemsetAsync(qb + (size_t)nq * x->d_pad, 0, (size_t)(plan.nq_pad - nq) * x->d_pad * sizeof(uint16_t), st));
+    }
+    MI_TRY(mi_launch_prep_queries(st, q_dev, nq, x->d, x->d_pad, x->dtype, x->q_canon.as<float>(), qb, x->qq.as<float>()));
+
+    x->st_queries += nq;
+    x->st_rows = n;
+    if (!fast) {
+        x->last_kind = 0;
+        MI_TRY(exact_search(x, st, x->q_canon.as<float>(), x->qq.as<float>(), nq, k, out_s, out_i, true));
+        x->st_exact += nq;
+        MI_HIP(hipStreamSynchronize(st));
+        return MI_OK;
+    }
+
+    // ---- MFMA scan + certificate
+    x->last_kind = 1;
+    MI_TRY(x->lists.ensure(plan.list_bytes));
+    MI_TRY(x->cnts.ensure(plan.cnt_bytes));
+    MI_TRY(x->thrs.ensure(plan.thr_bytes));
+    MI_TRY(x->fail.ensure((size_t)(nq + 64) * sizeof(int32_t)));
+    int32_t* fail_count = x->fail.as<int32_t>();
+    int32_t* fail_list = fail_count + 64;
+    MI_HIP(hipMemsetAsync(fail_count, 0, 256, st));
+    MI_TRY(ev_begin(x, st));
+    MI_TRY(mi_launch_mfma_scan(st, &plan, x->metric, (const uint16_t*)x->rows, x->xx, n, x->d_pad, qb, nq,
+                               x->lists.as<uint64_t>(), x->cnts.as<int32_t>(), x->thrs.as<float>()));
+    MI_TRY(ev_end(x, st));
+    MI_TRY(mi_launch_mfma_finish(st, &plan, x->metric, (const uint16_t*)x->rows, x->xx, x->max_xx, n, x->d_pad,
+                                 x->q_canon.as<float>(), x->qq.as<float>(), nq, k, x->id_base,
+                                 x->lists.as<uint64_t>(), x->cnts.as<int32_t>(), x->thrs.as<float>(),
+                                 out_s, out_i, fail_list, fail_count));
+    int32_t nfail = 0;
+    MI_HIP(hipMemcpyAsync(&nfail, fail_count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipStreamSynchronize(st));
+    x->st_fast += nq - nfail;
+    if (nfail > 0) {
+        // certificate failed for nfail queries: re-run exactly those on the exact path
+        x->st_exact += nfail;
+        MI_TRY(x->sub_q.ensure((size_t)nfail * x->d_pad * sizeof(float)));
+        MI_TRY(x->sub_qq.ensure((size_t)nfail * sizeof(float)));
+        MI_TRY(x->sub_s.ensure((size_t)nfail * k * sizeof(float)));
+        MI_TRY(x->sub_i.ensure((size_t)nfail * k * sizeof(int64_t)));
+        MI_TRY(mi_launch_gather_queries(st, fail_list, nfail, x->d_pad, x->q_canon.as<float>(), x->qq.as<float>(),
+                                        x->sub_q.as<float>(), x->sub_qq.as<float>()));
+        MI_TRY(exact_search(x, st, x->sub_q.as<float>(), x->sub_qq.as<float>(), nfail, k, x->sub_s.as<float>(), x->sub_i.as<int64_t>(), false));
+        MI_TRY(mi_launch_copy_lists(st, nfail, k, x->sub_s.as<float>(), x->sub_i.as<int64_t>(), k, fail_list, out_s, out_i, k));
+        MI_HIP(hipStreamSynchronize(st));
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_index_search_dev(mi_index* idx, int64_t nq, const float* q_dev, int k,
+                                   float* out_scores_dev, int64_t* out_ids_dev, void* stream)
+{
+    MI_REQUIRE(idx && (nq == 0 || (q_dev && out_scores_dev && out_ids_dev)), "mi_index_search_dev: NULL argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    DeviceGuard g(idx->ctx->device);
+    hipStream_t st = stream ? (hipStream_t)stream : idx->ctx->stream;
+    return search_dev_locked(idx, nq, q_dev, k, out_scores_dev, out_ids_dev, st);
+}
+
+extern "C" int mi_index_search(mi_index* idx, int64_t nq, const float* q_host, int k, float* out_scores, int64_t* out_ids)
+{
+    MI_REQUIRE(idx && (nq == 0 || (q_host && out_scores && out_ids)), "mi_index_search: NULL argument");
+    MI_REQUIRE(nq >= 0 && k >= 1, "mi_index_search: nq/k out of range");
+    if (nq == 0) return MI_OK;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    DeviceGuard g(idx->ctx->device);
+    hipStream_t st = idx->ctx->stream;
+    MI_TRY(idx->q_in.ensure((size_t)nq * idx->d * sizeof(float)));
+    MI_TRY(idx->out_s.ensure((size_t)nq * k * sizeof(float)));
+    MI_TRY(idx->out_i.ensure((size_t)nq * k * sizeof(int64_t)));
+    MI_HIP(hipMemcpyAsync(idx->q_in.p, q_host, (size_t)nq * idx->d * sizeof(float), hipMemcpyHostToDevice, st));
+    MI_TRY(search_dev_locked(idx, nq, idx->q_in.as<float>(), k, idx->out_s.as<float>(), idx->out_i.as<int64_t>(), st));
+    MI_HIP(hipMemcpyAsync(out_scores, idx->out_s.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipMemcpyAsync(out_ids, idx->out_i.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- merge of per-shard lists
+extern "C" int mi_topk_merge_dev(mi_ctx* ctx, int metric, int64_t nq, int nlists, int k_in,
+                                 const float* in_scores_dev, const int64_t* in_ids_dev,
+                                 int k, float* out_scores_dev, int64_t* out_ids_dev, void* stream)
+{
+    MI_REQUIRE(ctx && nq >= 0 && nlists >= 1 && k_in >= 1 && k >= 1, "mi_topk_merge_dev: bad argument");
+    MI_REQUIRE(metric == MI_METRIC_IP || metric == MI_METRIC_L2, "mi_topk_merge_dev: unknown metric");
+    if (nq == 0) return MI_OK;
+    MI_REQUIRE(in_scores_dev && in_ids_dev && out_scores_dev && out_ids_dev, "mi_topk_merge_dev: NULL buffer");
+    const int64_t m = (int64_t)nlists * k_in;
+    if (m > 4096) { mi_set_error("mi_topk_merge_dev: nlists*k_in = %lld exceeds 4096", (long long)m); return MI_ERR_UNSUPPORTED; }
+    DeviceGuard g(ctx->device);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    return mi_launch_merge(st, metric, nq, (int)m, in_scores_dev, in_ids_dev, m, k, out_scores_dev, out_ids_dev, k);
+}

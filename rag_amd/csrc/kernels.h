@@ -1,0 +1,61 @@
+// kernels.h — host-side launchers of the HIP kernels (internal to libmi355rag).
+#pragma once
+#include "common.h"
+
+// ---- ingest / synthetic data (ingest.hip)
+int mi_launch_ingest(hipStream_t st, const void* src, int src_dtype, int64_t n, int d, int d_pad,
+                     int dst_dtype, void* dst);
+int mi_launch_row_norms(hipStream_t st, const void* rows, int dtype, int64_t n, int d_pad,
+                        float* xx, float* max_xx);
+int mi_launch_synth(hipStream_t st, void* dst, int dtype, int64_t n, int d, int d_pad,
+                    uint64_t seed, int64_t row0, int normalize);
+int mi_launch_prep_queries(hipStream_t st, const float* q, int64_t nq, int d, int d_pad, int dtype,
+                           float* q_canon, uint16_t* q_bf16, float* qq);
+int mi_launch_export_rows(hipStream_t st, const void* rows, int dtype, int64_t n, int d, int d_pad,
+                          float* out);
+
+// ---- exact path (search_exact.hip)
+// S[qi][r] = canonical dot(q_canon[qi], row[row0 + r]), qi < nq, r < nrows.
+int mi_launch_scan_dense(hipStream_t st, const void* rows, int dtype, int64_t row0, int nrows,
+                         int d_pad, const float* q_canon, int nq, float* S, int64_t s_stride);
+// Per query: exact top-k of one dense segment, best-first, written at out[q*out_stride + j].
+// xx points at the segment's first row; id0 = id of the segment's first row.
+int mi_launch_select_dense(hipStream_t st, const float* S, int64_t s_stride, int nrows,
+                           const float* xx, const float* qq, int metric, int nq, int k,
+                           int64_t id0, float* out_s, int64_t* out_i, int64_t out_stride);
+// Per query: merge m (<= 4096) (score,id) entries (id < 0 = padding) into the k best.
+int mi_launch_merge(hipStream_t st, int metric, int64_t nq, int m, const float* in_s,
+                    const int64_t* in_i, int64_t in_stride, int k, float* out_s, int64_t* out_i,
+                    int64_t out_stride);
+int mi_launch_fill_pad(hipStream_t st, int metric, int64_t nq, int k, float* s, int64_t* i,
+                       int64_t stride);
+// out[dst_q[j]] rows <- in[j] rows (scatter of re-run queries); dst_q == nullptr: identity.
+int mi_launch_copy_lists(hipStream_t st, int64_t nq, int k, const float* in_s, const int64_t* in_i,
+                         int64_t in_stride, const int32_t* dst_q, float* out_s, int64_t* out_i,
+                         int64_t out_stride);
+// Gather rows of a [n][d_pad] fp32 matrix / scalars by index list.
+int mi_launch_gather_queries(hipStream_t st, const int32_t* sel, int nsel, int d_pad,
+                             const float* q_canon, const float* qq, float* q_out, float* qq_out);
+
+// ---- MFMA path (search_mfma.hip)
+struct mi_mfma_plan {
+    int kprime;        // candidates kept per (slice, query)
+    int cap;           // list capacity per (slice, query)
+    int nslices;       // row slices
+    int64_t slice_rows;// rows per slice (multiple of the tile height)
+    int nq_pad;        // queries padded to the query tile
+    size_t list_bytes, cnt_bytes, thr_bytes;
+};
+bool mi_mfma_supported(int d_pad, int k);
+int  mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* plan);
+// Phase 1: bf16 MFMA scan + threshold filter -> per-(slice,query) candidate lists.
+int  mi_launch_mfma_scan(hipStream_t st, const mi_mfma_plan* p, int metric, const uint16_t* rows,
+                         const float* xx, int64_t n, int d_pad, const uint16_t* q_bf16, int64_t nq,
+                         uint64_t* lists, int32_t* cnts, float* thrs);
+// Phase 2: canonical re-score of every candidate, exact top-k, certificate.
+// fail_flags[q] = 1 where the certificate does not hold; *fail_count accumulates them.
+int  mi_launch_mfma_finish(hipStream_t st, const mi_mfma_plan* p, int metric, const uint16_t* rows,
+                           const float* xx, const float* max_xx, int64_t n, int d_pad,
+                           const float* q_canon, const float* qq, int64_t nq, int k, int64_t id_base,
+                           const uint64_t* lists, const int32_t* cnts, const float* thrs,
+                           float* out_s, int64_t* out_i, int32_t* fail_list, int32_t* fail_count);

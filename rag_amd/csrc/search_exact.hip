@@ -1,0 +1,345 @@
+// search_exact.hip — the canonical-order exact scan (IndexFlat::search, advanced_rag.py:296):
+//   scan_dense  : S[q][r] = fmaf chain over k of q[k]*x_r[k]   (fp32 VALU, bit-exact definition)
+//   select_dense: per query, exact top-k of a dense segment by MSB radix select on the
+//                 64-bit key (rank word << 32 | ~row), then an LDS bitonic sort of the k winners
+//   merge       : per query, best k of up to 4096 (score,id) entries (segments, shards)
+// This is the ground-truth path: the MFMA scan (search_mfma.hip) falls back to it whenever
+// its certificate does not hold, and an F32 index uses it directly.
+#include "kernels.h"
+
+// ---------------------------------------------------------------- scan_dense
+// Workgroup = 256 threads = 256 rows x 16 queries.  Each k-chunk of 64 elements of the row
+// tile is fetched as whole 256-B (fp32) / 128-B (bf16) row segments, converted to fp32 and
+// parked in LDS with a 272-B row stride (conflict-free ds_read_b128 per row); the 16 query
+// chunks are broadcast reads.  Thread t owns row t: 16 independent fmaf chains, k ascending.
+// blockIdx.x walks the query groups so workgroups that share a row tile are dispatched
+// together and the tile is served from L2 after the first fetch.
+#define SD_ROWS 256
+#define SD_Q 16
+#define SD_KC 64
+
+template <typename T>
+__global__ __launch_bounds__(256) void scan_dense_kernel(const T* __restrict__ rows, int64_t row0, int nrows,
+                                                         int d_pad, const float* __restrict__ q_canon, int nq,
+                                                         float* __restrict__ S, int64_t s_stride)
+{
+    __shared__ float xs[SD_ROWS][SD_KC + 4];
+    __shared__ float qs[SD_Q][SD_KC];
+    const int t = threadIdx.x;
+    const int q0 = blockIdx.x * SD_Q;
+    const int r0 = blockIdx.y * SD_ROWS;
+    const T* base = rows + (row0 + r0) * (int64_t)d_pad;
+
+    float acc[SD_Q];
+#pragma unroll
+    for (int j = 0; j < SD_Q; ++j) acc[j] = 0.0f;
+
+    for (int k0 = 0; k0 < d_pad; k0 += SD_KC) {
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll 4
+            for (int p = 0; p < 16; ++p) {
+                const int r = p * 16 + (t >> 4), c = (t & 15) * 4;
+                float4 v = make_float4(0, 0, 0, 0);
+                if (r0 + r < nrows) v = *reinterpret_cast<const float4*>(base + (int64_t)r * d_pad + k0 + c);
+                *reinterpret_cast<float4*>(&xs[r][c]) = v;
+            }
+        } else {
+#pragma unroll 4
+            for (int p = 0; p < 8; ++p) {
+                const int r = p * 32 + (t >> 3), c = (t & 7) * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (r0 + r < nrows) v = *reinterpret_cast<const uint4*>(base + (int64_t)r * d_pad + k0 + c);
+                float4 lo, hi;
+                lo.x = __builtin_bit_cast(float, v.x << 16); lo.y = __builtin_bit_cast(float, v.x & 0xFFFF0000u);
+                lo.z = __builtin_bit_cast(float, v.y << 16); lo.w = __builtin_bit_cast(float, v.y & 0xFFFF0000u);
+                hi.x = __builtin_bit_cast(float, v.z << 16); hi.y = __builtin_bit_cast(float, v.z & 0xFFFF0000u);
+                hi.z = __builtin_bit_cast(float, v.w << 16); hi.w = __builtin_bit_cast(float, v.w & 0xFFFF0000u);
+                *reinterpret_cast<float4*>(&xs[r][c]) = lo;
+                *reinterpret_cast<float4*>(&xs[r][c + 4]) = hi;
+            }
+        }
+        {
+            const int j = t >> 4, c = (t & 15) * 4;   // 16 queries x 64 floats
+            float4 v = make_float4(0, 0, 0, 0);
+            if (q0 + j < nq) v = *reinterpret_cast<const float4*>(q_canon + (int64_t)(q0 + j) * d_pad + k0 + c);
+            *reinterpret_cast<float4*>(&qs[j][c]) = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < SD_KC; kk += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(&xs[t][kk]);
+#pragma unroll
+            for (int j = 0; j < SD_Q; ++j) {
+                const float4 qv = *reinterpret_cast<const float4*>(&qs[j][kk]);
+                float a = acc[j];
+                a = __builtin_fmaf(qv.x, xv.x, a);
+                a = __builtin_fmaf(qv.y, xv.y, a);
+                a = __builtin_fmaf(qv.z, xv.z, a);
+                a = __builtin_fmaf(qv.w, xv.w, a);
+                acc[j] = a;
+            }
+        }
+        __syncthreads();
+    }
+    if (r0 + t < nrows) {
+#pragma unroll
+        for (int j = 0; j < SD_Q; ++j)
+            if (q0 + j < nq) S[(int64_t)(q0 + j) * s_stride + r0 + t] = acc[j];
+    }
+}
+
+int mi_launch_scan_dense(hipStream_t st, const void* rows, int dtype, int64_t row0, int nrows, int d_pad,
+                         const float* q_canon, int nq, float* S, int64_t s_stride)
+{
+    if (nrows <= 0 || nq <= 0) return MI_OK;
+    dim3 grid((nq + SD_Q - 1) / SD_Q, (nrows + SD_ROWS - 1) / SD_ROWS);
+    if (grid.y > 65535) { mi_set_error("scan_dense: segment too long"); return MI_ERR_INTERNAL; }
+    if (dtype == MI_DTYPE_F32)
+        scan_dense_kernel<float><<<grid, 256, 0, st>>>((const float*)rows, row0, nrows, d_pad, q_canon, nq, S, s_stride);
+    else
+        scan_dense_kernel<uint16_t><<<grid, 256, 0, st>>>((const uint16_t*)rows, row0, nrows, d_pad, q_canon, nq, S, s_stride);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- LDS bitonic sort helpers
+// Sorts P (power of two) 64-bit keys descending.
+__device__ inline void bitonic_desc_u64(uint64_t* keys, int P, int t, int nt)
+{
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = t; i < (P >> 1); i += nt) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const uint64_t a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- select_dense
+#define SEL_THREADS 512
+
+__device__ inline uint64_t dense_key(const float* __restrict__ Srow, int i, const float* __restrict__ xx,
+                                     float qqv, int metric)
+{
+    const float dot = Srow[i];
+    const uint32_t rk = (metric == MI_METRIC_L2) ? mi_rank_l2(dot, qqv, xx[i]) : mi_rank_ip(dot);
+    return ((uint64_t)rk << 32) | (uint32_t)(~(uint32_t)i);
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_dense_kernel(const float* __restrict__ S, int64_t s_stride,
+        int nrows, const float* __restrict__ xx, const float* __restrict__ qq, int metric, int k, int64_t id0,
+        float* __restrict__ out_s, int64_t* __restrict__ out_i, int64_t out_stride)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t above[256];
+    __shared__ uint64_t s_prefix;
+    __shared__ int s_kk;
+    __shared__ int s_cnt;
+    __shared__ uint64_t keys[MI_MAX_K];
+
+    const int t = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    const float* Srow = S + q * s_stride;
+    const float qqv = qq[q];
+    float* os = out_s + q * out_stride;
+    int64_t* oi = out_i + q * out_stride;
+
+    int kk = (k < nrows) ? k : nrows;
+    const int nsel = kk;
+    uint64_t prefix = 0;
+    if (nsel > 0 && nsel < nrows) {
+        // MSB-first radix select, 8 bits a pass, on the unique 64-bit keys
+        for (int pass = 7; pass >= 0; --pass) {
+            if (t < 256) hist[t] = 0;
+            __syncthreads();
+            const int shift = pass * 8;
+            for (int i = t; i < nrows; i += SEL_THREADS) {
+                const uint64_t key = dense_key(Srow, i, xx, qqv, metric);
+                const bool match = (pass == 7) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                if (match) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            // above[b] = number of matching keys whose digit is > b (suffix scan, Hillis-Steele)
+            if (t < 256) above[t] = (t < 255) ? hist[t + 1] : 0;
+            __syncthreads();
+            for (int off = 1; off < 256; off <<= 1) {
+                uint32_t v = 0;
+                if (t < 256) v = above[t] + ((t + off < 256) ? above[t + off] : 0);
+                __syncthreads();
+                if (t < 256) above[t] = v;
+                __syncthreads();
+            }
+            if (t < 256) {
+                const uint32_t ab = above[t];
+                if (ab < (uint32_t)kk && (uint32_t)kk <= ab + hist[t]) {   // exactly one digit qualifies
+                    s_kk = kk - (int)ab;
+                    s_prefix = prefix | ((uint64_t)t << shift);
+                }
+            }
+            __syncthreads();
+            kk = s_kk;
+            prefix = s_prefix;
+            __syncthreads();
+        }
+    }
+    // collect every key >= prefix (exactly nsel of them; all rows when nsel == nrows)
+    if (t == 0) s_cnt = 0;
+    __syncthreads();
+    if (nsel > 0) {
+        for (int i = t; i < nrows; i += SEL_THREADS) {
+            const uint64_t key = dense_key(Srow, i, xx, qqv, metric);
+            if (key >= prefix) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < MI_MAX_K) keys[pos] = key;
+            }
+        }
+    }
+    __syncthreads();
+    const int P = (nsel > 1) ? (1 << (32 - __builtin_clz(nsel - 1))) : 1;
+    for (int i = nsel + t; i < P; i += SEL_THREADS) keys[i] = 0;
+    bitonic_desc_u64(keys, P, t, SEL_THREADS);
+    for (int j = t; j < k; j += SEL_THREADS) {
+        if (j < nsel) {
+            const uint64_t key = keys[j];
+            os[j] = mi_score_from_rank(metric, (uint32_t)(key >> 32));
+            oi[j] = id0 + (int64_t)(uint32_t)(~(uint32_t)key);
+        } else {
+            os[j] = mi_pad_score(metric);
+            oi[j] = -1;
+        }
+    }
+}
+
+int mi_launch_select_dense(hipStream_t st, const float* S, int64_t s_stride, int nrows, const float* xx,
+                           const float* qq, int metric, int nq, int k, int64_t id0, float* out_s,
+                           int64_t* out_i, int64_t out_stride)
+{
+    if (nq <= 0) return MI_OK;
+    select_dense_kernel<<<nq, SEL_THREADS, 0, st>>>(S, s_stride, nrows, xx, qq, metric, k, id0, out_s, out_i, out_stride);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- merge
+// Order: rank word descending, then id ascending.  rank word 0 never occurs for a valid
+// entry (NaN is canonicalised), so it marks padding.
+#define MERGE_MAX 4096
+#define MERGE_THREADS 256
+
+__global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(int metric, int m, int P,
+        const float* __restrict__ in_s, const int64_t* __restrict__ in_i, int64_t in_stride, int k,
+        float* __restrict__ out_s, int64_t* __restrict__ out_i, int64_t out_stride)
+{
+    __shared__ uint32_t rk[MERGE_MAX];
+    __shared__ int64_t id[MERGE_MAX];
+    const int t = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    for (int i = t; i < P; i += MERGE_THREADS) {
+        uint32_t r = 0;
+        int64_t v = INT64_MAX;
+        if (i < m) {
+            const int64_t x = in_i[q * in_stride + i];
+            if (x >= 0) {
+                float s = in_s[q * in_stride + i];
+                if (metric == MI_METRIC_L2) { if (s != s) s = __builtin_inff(); s += 0.0f; r = ~mi_ord_f32(s); }
+                else { if (s != s) s = -__builtin_inff(); s += 0.0f; r = mi_ord_f32(s); }
+                v = x;
+            }
+        }
+        rk[i] = r;
+        id[i] = v;
+    }
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = t; i < (P >> 1); i += MERGE_THREADS) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const uint32_t ra = rk[lo], rb = rk[hi];
+                const int64_t ia = id[lo], ib = id[hi];
+                const bool a_worse = (ra < rb) || (ra == rb && ia > ib);
+                if (a_worse == desc && !(ra == rb && ia == ib)) { rk[lo] = rb; rk[hi] = ra; id[lo] = ib; id[hi] = ia; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = t; j < k; j += MERGE_THREADS) {
+        const bool valid = (j < P) && id[j] != INT64_MAX;
+        out_s[q * out_stride + j] = valid ? mi_score_from_rank(metric, rk[j]) : mi_pad_score(metric);
+        out_i[q * out_stride + j] = valid ? id[j] : -1;
+    }
+}
+
+int mi_launch_merge(hipStream_t st, int metric, int64_t nq, int m, const float* in_s, const int64_t* in_i,
+                    int64_t in_stride, int k, float* out_s, int64_t* out_i, int64_t out_stride)
+{
+    if (nq <= 0) return MI_OK;
+    if (m > MERGE_MAX) { mi_set_error("merge: %d entries per query exceeds %d", m, MERGE_MAX); return MI_ERR_INTERNAL; }
+    const int P = mi_next_pow2(m > 1 ? m : 1);
+    merge_kernel<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(metric, m, P, in_s, in_i, in_stride, k, out_s, out_i, out_stride);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- small list utilities
+__global__ __launch_bounds__(256) void fill_pad_kernel(int metric, int64_t nq, int k, float* s, int64_t* i, int64_t stride)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= nq * k) return;
+    const int64_t q = g / k;
+    const int j = (int)(g - q * k);
+    s[q * stride + j] = mi_pad_score(metric);
+    i[q * stride + j] = -1;
+}
+int mi_launch_fill_pad(hipStream_t st, int metric, int64_t nq, int k, float* s, int64_t* i, int64_t stride)
+{
+    if (nq <= 0) return MI_OK;
+    fill_pad_kernel<<<(unsigned)((nq * k + 255) / 256), 256, 0, st>>>(metric, nq, k, s, i, stride);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+__global__ __launch_bounds__(256) void copy_lists_kernel(int64_t nq, int k, const float* __restrict__ in_s,
+        const int64_t* __restrict__ in_i, int64_t in_stride, const int32_t* __restrict__ dst_q,
+        float* __restrict__ out_s, int64_t* __restrict__ out_i, int64_t out_stride)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= nq * k) return;
+    const int64_t q = g / k;
+    const int j = (int)(g - q * k);
+    const int64_t dq = dst_q ? (int64_t)dst_q[q] : q;
+    out_s[dq * out_stride + j] = in_s[q * in_stride + j];
+    out_i[dq * out_stride + j] = in_i[q * in_stride + j];
+}
+int mi_launch_copy_lists(hipStream_t st, int64_t nq, int k, const float* in_s, const int64_t* in_i,
+                         int64_t in_stride, const int32_t* dst_q, float* out_s, int64_t* out_i, int64_t out_stride)
+{
+    if (nq <= 0) return MI_OK;
+    copy_lists_kernel<<<(unsigned)((nq * k + 255) / 256), 256, 0, st>>>(nq, k, in_s, in_i, in_stride, dst_q, out_s, out_i, out_stride);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+__global__ __launch_bounds__(256) void gather_queries_kernel(const int32_t* __restrict__ sel, int nsel, int d_pad,
+        const float* __restrict__ q_canon, const float* __restrict__ qq, float* __restrict__ q_out, float* __restrict__ qq_out)
+{
+    const int j = blockIdx.x;
+    const int64_t src = sel[j];
+    for (int c = threadIdx.x; c < d_pad; c += 256) q_out[(int64_t)j * d_pad + c] = q_canon[src * d_pad + c];
+    if (threadIdx.x == 0) qq_out[j] = qq[src];
+}
+int mi_launch_gather_queries(hipStream_t st, const int32_t* sel, int nsel, int d_pad, const float* q_canon,
+                             const float* qq, float* q_out, float* qq_out)
+{
+    if (nsel <= 0) return MI_OK;
+    gather_queries_kernel<<<nsel, 256, 0, st>>>(sel, nsel, d_pad, q_canon, qq, q_out, qq_out);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}

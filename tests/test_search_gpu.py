@@ -1,0 +1,132 @@
+"""GPU parity: the HIP flat-search path (through the C-ABI) against the CPU oracle.
+
+Bar: bit-exact ids AND bit-exact scores (integer/index work + a fixed fp32 summation order).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+def _check(oracle, X, Q, k, metric, dtype, mode=None, id_base=0):
+    from rag_amd.index import FlatIndex, MODE_EXACT
+    idx = FlatIndex(X.shape[1], metric=metric, dtype=dtype)
+    if id_base:
+        idx.set_id_base(id_base)
+    if mode is not None:
+        idx.set_mode(mode)
+    if len(X):
+        idx.add(X)
+    D, I = idx.search(Q, k)
+    m = {"ip": oracle.METRIC_IP, "l2": oracle.METRIC_L2}[metric]
+    t = {"f32": oracle.DTYPE_F32, "bf16": oracle.DTYPE_BF16}[dtype]
+    Do, Io = oracle.search(X.reshape(-1, Q.shape[1]), Q, k, metric=m, dtype=t, id_base=id_base)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+    return idx
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("n,d,nq,k", [(1000, 384, 7, 5), (5000, 64, 33, 10), (300, 100, 3, 4), (70000, 384, 20, 10)])
+def test_exact_path_matches_oracle(oracle_mod, metric, dtype, n, d, nq, k):
+    from rag_amd.index import MODE_EXACT
+    rng = np.random.default_rng(n + d)
+    _check(oracle_mod, _unit(rng, n, d), _unit(rng, nq, d), k, metric, dtype, mode=MODE_EXACT)
+
+
+def test_k_larger_than_n_and_empty(oracle_mod):
+    rng = np.random.default_rng(1)
+    X, Q = _unit(rng, 3, 32), _unit(rng, 2, 32)
+    for metric in ("ip", "l2"):
+        _check(oracle_mod, X, Q, 8, metric, "f32")
+        _check(oracle_mod, X[:0], Q, 4, metric, "f32")
+
+
+def test_ties_and_duplicates_lower_id_first(oracle_mod):
+    rng = np.random.default_rng(2)
+    X = _unit(rng, 2000, 128)
+    X[100:140] = X[7]          # 41 identical rows
+    X[1500] = X[7]
+    Q = np.concatenate([X[7:8], _unit(rng, 4, 128)])
+    for metric in ("ip", "l2"):
+        for dtype in ("f32", "bf16"):
+            _check(oracle_mod, X, Q, 50, metric, dtype)
+
+
+def test_id_base_offsets_labels(oracle_mod):
+    rng = np.random.default_rng(3)
+    _check(oracle_mod, _unit(rng, 500, 64), _unit(rng, 5, 64), 6, "ip", "f32", id_base=10**10)
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(40000, 384, 300, 10), (100000, 128, 64, 5), (50000, 384, 5, 10),
+                                       (66000, 768, 40, 10), (40000, 384, 50, 100), (40000, 384, 17, 20)])
+def test_mfma_path_matches_oracle(oracle_mod, n, d, nq, k):
+    from rag_amd.index import MODE_FAST
+    rng = np.random.default_rng(n + d + k)
+    idx = _check(oracle_mod, _unit(rng, n, d), _unit(rng, nq, d), k, "ip", "bf16", mode=MODE_FAST)
+    st = idx.stats()
+    assert st["fast"] + st["exact"] == nq
+    assert st["fast"] >= nq * 0.9, st          # random data: the certificate should nearly always hold
+
+
+def test_mfma_certificate_falls_back_on_duplicates(oracle_mod):
+    """More identical rows than the candidate lists hold: the certificate cannot hold for that
+    query, so it must be re-run on the exact path and still be bit-exact."""
+    from rag_amd.index import MODE_FAST
+    rng = np.random.default_rng(5)
+    X = _unit(rng, 40000, 384)
+    X[1000:1400] = X[3]
+    Q = np.concatenate([X[3:4], _unit(rng, 9, 384)])
+    idx = _check(oracle_mod, X, Q, 10, "ip", "bf16", mode=MODE_FAST)
+    assert idx.stats()["exact"] >= 1
+
+
+def test_mfma_clustered_rows(oracle_mod):
+    """Scores that rise along the scan (a topic cluster at the end of the corpus) exercise the
+    in-kernel list compaction."""
+    from rag_amd.index import MODE_FAST
+    rng = np.random.default_rng(6)
+    n, d = 60000, 384
+    X = _unit(rng, n, d)
+    Q = _unit(rng, 12, d)
+    ramp = np.linspace(0.0, 0.6, n).astype(np.float32)[:, None]
+    X = X + ramp * Q[0][None, :]
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    _check(oracle_mod, X.astype(np.float32), Q, 10, "ip", "bf16", mode=MODE_FAST)
+
+
+def test_synthetic_rows_match_oracle_generator(oracle_mod):
+    from rag_amd.index import FlatIndex
+    for dtype in ("f32", "bf16"):
+        idx = FlatIndex(384, metric="ip", dtype=dtype)
+        idx.set_id_base(1000)
+        idx.add_synthetic(300, seed=7)
+        got = idx.reconstruct_n(0, 300)
+        want = oracle_mod.synth_rows(7, 1000, 300, 384)
+        if dtype == "bf16":
+            want = oracle_mod.bf16_to_f32(oracle_mod.round_bf16(want))
+        np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_merge_matches_oracle(oracle_mod):
+    import torch
+    from rag_amd.index import topk_merge_torch
+    rng = np.random.default_rng(8)
+    nq, m, k = 37, 80, 10
+    s = rng.standard_normal((nq, m)).astype(np.float32)
+    s[:, 5] = s[:, 6]                                   # ties
+    ids = rng.permutation(10**6)[: nq * m].reshape(nq, m).astype(np.int64)
+    ids[:, 70:] = -1                                    # padding
+    for metric, om in (("ip", oracle_mod.METRIC_IP), ("l2", oracle_mod.METRIC_L2)):
+        ss = np.abs(s) if metric == "l2" else s
+        D, I = topk_merge_torch(torch.from_numpy(ss).cuda(), torch.from_numpy(ids).cuda(), k, metric)
+        Do, Io = oracle_mod.topk_merge(ss, ids, k, om)
+        np.testing.assert_array_equal(I.cpu().numpy(), Io)
+        np.testing.assert_array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))
