@@ -84,6 +84,14 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -m rag_amd._build` "
                 "(or __graft_entry__.build()).  rag_amd has no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7, and a
+        # process that loads /opt/rocm's copy first and torch's second ends up with two
+        # runtimes, the second of which sees no GPU.  Importing torch first makes the dynamic
+        # loader satisfy our NEEDED libamdhip64.so.7 with the copy torch already mapped.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)          # AttributeError if the .so does not export it
