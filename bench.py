@@ -45,8 +45,8 @@ def main() -> int:
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=1_000_000)
-    ap.add_argument("--cpu-queries", type=int, default=512)
+    ap.add_argument("--cpu-rows", type=int, default=2_000_000)
+    ap.add_argument("--cpu-queries", type=int, default=4096)
     ap.add_argument("--check", type=int, default=8, help="queries verified against the oracle on the CPU sample rows")
     args = ap.parse_args()
 
@@ -93,11 +93,12 @@ def main() -> int:
     def step():
         D, I = idx.search_torch(q_dev, k)
         if world > 1:
-            Dg = torch.empty((world, Q, k), dtype=D.dtype, device=dev)
-            Ig = torch.empty((world, Q, k), dtype=I.dtype, device=dev)
+            Dg = torch.empty((world * Q, k), dtype=D.dtype, device=dev)      # rank-major concat
+            Ig = torch.empty((world * Q, k), dtype=I.dtype, device=dev)
             dist.all_gather_into_tensor(Dg, D)
             dist.all_gather_into_tensor(Ig, I)
-            D, I = topk_merge_torch(Dg.permute(1, 0, 2).reshape(Q, world * k), Ig.permute(1, 0, 2).reshape(Q, world * k), k, "ip")
+            D, I = topk_merge_torch(Dg.view(world, Q, k).permute(1, 0, 2).reshape(Q, world * k),
+                                    Ig.view(world, Q, k).permute(1, 0, 2).reshape(Q, world * k), k, "ip")
         return D, I
 
     for _ in range(args.warmup):

@@ -1,0 +1,77 @@
+"""CPU, world_size 2, gloo: the row-shard + all-gather + merge path of
+rag_amd.distributed.ShardedFlatIndex equals the single-index answer."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, metric, dtype, n, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from rag_amd.distributed import ShardedFlatIndex, shard_range
+    from tests._fakes import OracleIndex
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(42)                      # same corpus/queries on every rank
+        X = rng.integers(-4, 5, size=(n, 24)).astype(np.float32)   # integer data: plenty of exact ties
+        Q = rng.integers(-4, 5, size=(9, 24)).astype(np.float32)
+        m = {"ip": oracle.METRIC_IP, "l2": oracle.METRIC_L2}[metric]
+
+        def merge(Dm, Im, k, metric_name):
+            D, I = oracle.topk_merge(Dm.numpy(), Im.numpy(), k, m)
+            return torch.from_numpy(D), torch.from_numpy(I)
+
+        sh = ShardedFlatIndex(24, metric=metric, dtype=dtype, local_index=OracleIndex(24, metric, dtype), merge_fn=merge)
+        sh.add_global(X)
+        lo, hi = shard_range(n, world, rank)
+        assert sh.local.ntotal == hi - lo and sh.local.id_base == lo
+        for k in (1, 5, 40):
+            D, I = sh.search(Q, k)
+            np.save(os.path.join(out_dir, f"D_{rank}_{k}.npy"), D)
+            np.save(os.path.join(out_dir, f"I_{rank}_{k}.npy"), I)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric,dtype,n", [("ip", "f32", 101), ("l2", "bf16", 64), ("ip", "bf16", 3)])
+def test_two_rank_sharded_search_equals_single_index(tmp_path, oracle_mod, metric, dtype, n):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, metric, dtype, n, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(42)
+    X = rng.integers(-4, 5, size=(n, 24)).astype(np.float32)
+    Q = rng.integers(-4, 5, size=(9, 24)).astype(np.float32)
+    m = {"ip": oracle_mod.METRIC_IP, "l2": oracle_mod.METRIC_L2}[metric]
+    t = {"f32": oracle_mod.DTYPE_F32, "bf16": oracle_mod.DTYPE_BF16}[dtype]
+    for k in (1, 5, 40):
+        Dw, Iw = oracle_mod.search(X, Q, k, metric=m, dtype=t)
+        for rank in (0, 1):                                   # every rank holds the identical, exact answer
+            D = np.load(tmp_path / f"D_{rank}_{k}.npy")
+            I = np.load(tmp_path / f"I_{rank}_{k}.npy")
+            np.testing.assert_array_equal(I, Iw)
+            np.testing.assert_array_equal(D.view(np.uint32), Dw.view(np.uint32))
+
+
+def test_shard_ranges_partition_the_rows():
+    from rag_amd.distributed import shard_range
+    for n in (0, 1, 7, 100, 100_000_001):
+        for world in (1, 2, 4, 8):
+            r = [shard_range(n, world, i) for i in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
