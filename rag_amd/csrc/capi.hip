@@ -28,6 +28,9 @@ struct mi_ctx {
     std::mutex mu;
 };
 
+int mi_ctx_device(mi_ctx* ctx) { return ctx->device; }
+hipStream_t mi_ctx_stream(mi_ctx* ctx) { return ctx->stream; }
+
 // grow-only device buffer
 struct DevBuf {
     void* p = nullptr;

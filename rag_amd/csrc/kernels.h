@@ -2,6 +2,10 @@
 #pragma once
 #include "common.h"
 
+// ---- context accessors (capi.hip owns struct mi_ctx)
+int mi_ctx_device(mi_ctx* ctx);
+hipStream_t mi_ctx_stream(mi_ctx* ctx);
+
 // ---- ingest / synthetic data (ingest.hip)
 int mi_launch_ingest(hipStream_t st, const void* src, int src_dtype, int64_t n, int d, int d_pad,
                      int dst_dtype, void* dst);

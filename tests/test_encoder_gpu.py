@@ -1,0 +1,101 @@
+"""GPU parity: the HIP encoder (through the C-ABI) against the fp32 CPU oracle and the committed
+transformers-BertModel fixture.  Bar (BASELINE.json north_star): 1 - cosine <= 1e-3."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "encoder_small.npz")
+TOL = 1e-3
+
+
+def _cos_err(a, b):
+    return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+def _cfgs(oracle, *vals):
+    from rag_amd._capi import BertConfig
+    return BertConfig(*vals), oracle.BertConfig(*vals)
+
+
+def test_matches_bertmodel_fixture(oracle_mod):
+    from rag_amd.embeddings import Encoder
+    g = np.load(GOLD)
+    c = [int(v) for v in g["config"]]
+    cfg, _ = _cfgs(oracle_mod, c[0], c[1], c[2], c[3], c[4], c[5], c[6], float(g["layer_norm_eps"]), 1)
+    enc = Encoder(cfg, g["blob"])
+    E = enc.encode_ids(g["ids"], g["mask"])
+    err = _cos_err(E, g["embeddings"])
+    assert np.all(err < TOL), err
+    assert np.abs(np.linalg.norm(E, axis=1) - 1).max() < 1e-5
+
+
+@pytest.mark.parametrize("B,L", [(3, 256), (5, 100), (9, 33), (2, 512), (1, 1)])
+def test_minilm_dims_match_oracle(oracle_mod, B, L):
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import random_blob
+    cfg, ocfg = _cfgs(oracle_mod, 2000, 384, 6, 12, 1536, 512, 2, 1e-12, 1)
+    blob = random_blob(cfg, seed=3, init_range=0.05)
+    rng = np.random.default_rng(B * 1000 + L)
+    ids = rng.integers(0, 2000, size=(B, L)).astype(np.int32)
+    mask = np.ones((B, L), dtype=np.int32)
+    for b in range(1, B):
+        mask[b, rng.integers(1, L + 1):] = 0           # ragged lengths, at least one token
+    enc = Encoder(cfg, blob)
+    E = enc.encode_ids(ids, mask)
+    Eo = oracle_mod.encode(ocfg, blob, ids, mask)
+    err = _cos_err(E, Eo)
+    assert np.all(err < TOL), err
+    assert enc.last_time_ms() > 0
+
+
+def test_unnormalised_and_all_masked(oracle_mod):
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import random_blob
+    cfg, ocfg = _cfgs(oracle_mod, 500, 128, 2, 4, 256, 64, 2, 1e-12, 0)
+    blob = random_blob(cfg, seed=1, init_range=0.1)
+    rng = np.random.default_rng(0)
+    ids = rng.integers(0, 500, size=(3, 20)).astype(np.int32)
+    mask = np.ones((3, 20), dtype=np.int32)
+    mask[2] = 0                                        # all-masked sequence -> zero vector
+    enc = Encoder(cfg, blob)
+    E = enc.encode_ids(ids, mask)
+    Eo = oracle_mod.encode(ocfg, blob, ids, mask)
+    assert np.all(E[2] == 0) and np.all(Eo[2] == 0)
+    assert np.all(_cos_err(E[:2], Eo[:2]) < TOL)
+    assert np.abs(E[:2] - Eo[:2]).max() < 0.05 * np.abs(Eo[:2]).max()
+
+
+def test_bad_inputs_fail_loudly():
+    from rag_amd import MI355Error
+    from rag_amd._capi import BertConfig
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import random_blob
+    cfg = BertConfig(100, 128, 1, 4, 128, 32, 2, 1e-12, 1)
+    enc = Encoder(cfg, random_blob(cfg))
+    ids = np.zeros((1, 8), dtype=np.int32)
+    ids[0, 3] = 100
+    with pytest.raises(MI355Error):
+        enc.encode_ids(ids, np.ones_like(ids))
+    with pytest.raises(MI355Error):
+        enc.encode_ids(np.zeros((1, 33), dtype=np.int32), np.ones((1, 33), dtype=np.int32))   # L > max_pos
+    with pytest.raises(MI355Error):
+        Encoder(BertConfig(100, 128, 1, 2, 128, 32, 2, 1e-12, 1), random_blob(BertConfig(100, 128, 1, 2, 128, 32, 2, 1e-12, 1)))  # head size 64
+
+
+def test_device_pointer_variant_matches_host_variant():
+    import torch
+    from rag_amd._capi import BertConfig
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import random_blob
+    cfg = BertConfig(1000, 384, 2, 12, 1536, 512, 2, 1e-12, 1)
+    enc = Encoder(cfg, random_blob(cfg, seed=5, init_range=0.05))
+    rng = np.random.default_rng(1)
+    ids = rng.integers(0, 1000, size=(6, 64)).astype(np.int32)
+    mask = np.ones_like(ids)
+    mask[3, 10:] = 0
+    E = enc.encode_ids(ids, mask)
+    Et = enc.encode_ids_torch(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(E, Et.cpu().numpy())
