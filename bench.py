@@ -34,6 +34,56 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def bench_embed(args, dev, rank, world, barrier):
+    """Second half of BASELINE.json's metric: chunks/s, bulk embedding of 256-token chunks with a
+    MiniLM-L6 encoder (seeded random weights, synthetic token ids), data-parallel, no collective."""
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import minilm_l6_config, random_blob
+    cfg = minilm_l6_config()
+    blob = random_blob(cfg, seed=0, init_range=0.02)
+    enc = Encoder(cfg, blob, device=dev.index)
+    B, L = args.embed_chunks, 256
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    ids = torch.randint(1000, 30000, (B, L), generator=g, dtype=torch.int32).to(dev)
+    mask = torch.ones((B, L), dtype=torch.int32, device=dev)
+    enc.encode_ids_torch(ids[:256], mask[:256])          # warm-up
+    barrier()
+    t0 = time.perf_counter()
+    ms = 0.0
+    for _ in range(args.embed_steps):
+        E = enc.encode_ids_torch(ids, mask)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    chunks = B * args.embed_steps * world
+    H, I, nl = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    flop_chunk = nl * L * (8 * H * H + 4 * H * I + 4 * L * H)        # SURVEY.md §8d: 6.04 GFLOP
+    res = {"metric": "chunks/s embed (256-token chunks, MiniLM-L6, bf16 MFMA)", "value": round(chunks / el, 1),
+           "unit": "chunks/s", "chunks_per_step_per_gpu": B, "steps": args.embed_steps,
+           "roofline": {"bound": "mfma", "achieved": round(chunks / el * flop_chunk / 1e12 / world, 2),
+                        "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(chunks / el * flop_chunk / 1e12 / world / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                        "note": "whole encoder forward (all kernels), algorithmic 6.04 GFLOP per chunk"},
+           "cpu_baseline": None}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        ocfg = oracle.BertConfig(*[getattr(cfg, f) for f, _ in type(cfg)._fields_])
+        nb = 2 * oracle.num_threads()
+        tc = time.perf_counter()
+        Eo = oracle.encode(ocfg, blob, ids[:nb].cpu().numpy(), mask[:nb].cpu().numpy())
+        tcpu = time.perf_counter() - tc
+        Eg = E[:nb].cpu().numpy()
+        cos = (Eg * Eo).sum(1) / (np.linalg.norm(Eg, axis=1) * np.linalg.norm(Eo, axis=1))
+        res["cpu_baseline"] = {"value": round(nb / tcpu, 3), "unit": "chunks/s", "cores": oracle.num_threads(), "kind": "port",
+                               "sample": f"oracle.encode (fp32 C port of BertModel + mean-pool) on {nb} of the same chunks in {tcpu:.1f}s"}
+        res["parity_check"] = {"chunks": nb, "max_1_minus_cos_vs_oracle": float((1 - cos).max())}
+    return res
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,6 +98,9 @@ def main() -> int:
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
     ap.add_argument("--cpu-queries", type=int, default=4096)
     ap.add_argument("--check", type=int, default=8, help="queries verified against the oracle on the CPU sample rows")
+    ap.add_argument("--embed-chunks", type=int, default=4096, help="256-token chunks per rank per embed step (0 = skip)")
+    ap.add_argument("--embed-steps", type=int, default=3)
+    ap.add_argument("--embed-only", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -63,6 +116,19 @@ def main() -> int:
         dist.init_process_group("nccl", device_id=dev)
 
     from rag_amd.index import FlatIndex, topk_merge_torch
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.embed_only:
+        res = bench_embed(args, dev, rank, world, barrier)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
 
     N, d, Q, k = args.rows, args.dim, args.queries, args.k
     shard = (N + ngpu - 1) // ngpu
@@ -82,11 +148,6 @@ def main() -> int:
     q_dev = torch.from_numpy(q_host).to(dev)
     torch.cuda.synchronize()
     log(f"[rank {rank}] corpus shard {nloc} x {d} {args.dtype} + {Q} queries ready in {time.time() - t0:.1f}s")
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     scan_ms, scan_launches = [], []
 
@@ -118,6 +179,11 @@ def main() -> int:
         elapsed = float(t.item())
     stats = idx.stats()
     kind = idx.last_scan_time()["kind"]
+    embed = None
+    if args.embed_chunks > 0:
+        nloc_keep = nloc
+        D_keep, I_keep = D, I
+        embed = bench_embed(args, dev, rank, world, barrier)
 
     if rank != 0:
         if world > 1:
@@ -190,6 +256,8 @@ def main() -> int:
     }
     if check is not None:
         out["parity_check"] = check
+    if embed is not None:
+        out["embed"] = embed
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
