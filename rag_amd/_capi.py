@@ -11,7 +11,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmi355rag.so")
+# MI355RAG_LIB: another build of the same library (A/B timing of two builds on one device)
+LIB_PATH = os.environ.get("MI355RAG_LIB") or os.path.join(_HERE, "lib", "libmi355rag.so")
 
 MI_OK = 0
 METRIC_IP, METRIC_L2 = 0, 1

@@ -52,13 +52,18 @@ struct DevBuf {
 struct mi_index {
     mi_ctx* ctx = nullptr;
     int d = 0, d_pad = 0, metric = 0, dtype = 0, mode = MI_MODE_AUTO;
+    int d_pad_scan = 0;         // row pitch the MFMA scan streams (128/384/768), 0 = no MFMA path
     int64_t n = 0, cap_rows = 0, id_base = 0;
     void* rows = nullptr;       // [cap_rows][d_pad] fp32 or bf16
+    // F32 index only: bf16 (RNE) shadow of the rows, [shadow_cap][d_pad_scan], built lazily by the
+    // first fast search and kept up to row shadow_n.  The scan filters on it; scores never come from it.
+    DevBuf shadow;
+    int64_t shadow_n = 0, shadow_cap = 0;
     float* xx = nullptr;        // [cap_rows] canonical squared norms
     float* max_xx = nullptr;    // device scalar: max over rows of xx
     std::mutex mu;
     // search workspace (grow-only)
-    DevBuf q_in, q_canon, q_bf16, qq, dense, pair_s, pair_i, lists, cnts, thrs, fail, sub_q, sub_qq, sub_s, sub_i, out_s, out_i;
+    DevBuf q_in, q_canon, q_bf16, qq, dense, pair_s, pair_i, lists, cnts, thrs, gthr, fail, part_s, part_i, sub_q, sub_qq, sub_s, sub_i, out_s, out_i;
     // stats
     int64_t st_queries = 0, st_fast = 0, st_exact = 0, st_rows = 0;
     // scan timing of the last search
@@ -134,10 +139,8 @@ extern "C" int mi_index_create(mi_ctx* ctx, int dim, int metric, int dtype, mi_i
     x->ctx = ctx; x->d = dim; x->metric = metric; x->dtype = dtype;
     x->d_pad = mi_pad_dim(dim);
     // the MFMA scan is built for 128 / 384 / 768-element rows: pad a BF16 index up to the next one
-    if (dtype == MI_DTYPE_BF16) {
-        if (x->d_pad > 128 && x->d_pad < 384) x->d_pad = 384;
-        else if (x->d_pad > 384 && x->d_pad < 768) x->d_pad = 768;
-    }
+    x->d_pad_scan = mi_mfma_pitch(dim);
+    if (dtype == MI_DTYPE_BF16 && x->d_pad_scan) x->d_pad = x->d_pad_scan;
     hipError_t e = hipMalloc((void**)&x->max_xx, 256);
     if (e != hipSuccess) { delete x; mi_set_error("mi_index_create: hipMalloc failed: %s", hipGetErrorString(e)); return MI_ERR_OOM; }
     e = hipMemsetAsync(x->max_xx, 0, 256, ctx->stream);
@@ -156,8 +159,8 @@ extern "C" void mi_index_destroy(mi_index* idx)
     if (idx->xx) (void)hipFree(idx->xx);
     if (idx->max_xx) (void)hipFree(idx->max_xx);
     DevBuf* bufs[] = {&idx->q_in, &idx->q_canon, &idx->q_bf16, &idx->qq, &idx->dense, &idx->pair_s, &idx->pair_i,
-                      &idx->lists, &idx->cnts, &idx->thrs, &idx->fail, &idx->sub_q, &idx->sub_qq, &idx->sub_s,
-                      &idx->sub_i, &idx->out_s, &idx->out_i};
+                      &idx->lists, &idx->cnts, &idx->thrs, &idx->gthr, &idx->fail, &idx->part_s, &idx->part_i, &idx->sub_q, &idx->sub_qq,
+                      &idx->sub_s, &idx->sub_i, &idx->out_s, &idx->out_i, &idx->shadow};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t ev : idx->ev_pool) (void)hipEventDestroy(ev);
     delete idx;
@@ -214,7 +217,7 @@ extern "C" int mi_index_add_dev(mi_index* idx, int64_t n, const void* x_dev, int
     DeviceGuard g(idx->ctx->device);
     hipStream_t st = stream ? (hipStream_t)stream : idx->ctx->stream;
     MI_TRY(grow_for(idx, n));
-    MI_TRY(mi_launch_ingest(st, x_dev, src_dtype, n, idx->d, idx->d_pad, idx->dtype, row_ptr(idx, idx->n)));
+    MI_TRY(mi_launch_ingest(st, x_dev, src_dtype, idx->d, n, idx->d, idx->d_pad, idx->dtype, row_ptr(idx, idx->n)));
     MI_TRY(mi_launch_row_norms(st, row_ptr(idx, idx->n), idx->dtype, n, idx->d_pad, idx->xx + idx->n, idx->max_xx));
     idx->n += n;
     return MI_OK;
@@ -284,6 +287,7 @@ extern "C" int mi_index_reset(mi_index* idx)
     std::lock_guard<std::mutex> lk(idx->mu);
     DeviceGuard g(idx->ctx->device);
     idx->n = 0;
+    idx->shadow_n = 0;
     MI_HIP(hipMemsetAsync(idx->max_xx, 0, 256, idx->ctx->stream));
     MI_HIP(hipStreamSynchronize(idx->ctx->stream));
     return MI_OK;
@@ -410,6 +414,24 @@ static int exact_search(mi_index* x, hipStream_t st, const float* q_canon, const
 }
 
 // ---------------------------------------------------------------- search: orchestration
+// F32 index: bring the bf16 shadow up to date with rows [0, n).
+static int ensure_shadow(mi_index* x, hipStream_t st)
+{
+    if (x->shadow_cap < x->cap_rows) {
+        MI_HIP(hipStreamSynchronize(st));
+        MI_TRY(x->shadow.ensure((size_t)x->cap_rows * x->d_pad_scan * sizeof(uint16_t)));
+        x->shadow_cap = x->cap_rows;
+        x->shadow_n = 0;
+    }
+    if (x->shadow_n < x->n) {
+        const int64_t m = x->n - x->shadow_n;
+        MI_TRY(mi_launch_ingest(st, (const float*)x->rows + x->shadow_n * x->d_pad, MI_DTYPE_F32, x->d_pad, m, x->d, x->d_pad_scan,
+                                MI_DTYPE_BF16, x->shadow.as<uint16_t>() + x->shadow_n * x->d_pad_scan));
+        x->shadow_n = x->n;
+    }
+    return MI_OK;
+}
+
 static int search_dev_locked(mi_index* x, int64_t nq64, const float* q_dev, int k, float* out_s, int64_t* out_i, hipStream_t st)
 {
     MI_REQUIRE(nq64 >= 0 && nq64 < ((int64_t)1 << 24), "search: nq %lld out of range", (long long)nq64);
@@ -422,26 +444,28 @@ static int search_dev_locked(mi_index* x, int64_t nq64, const float* q_dev, int 
 
     bool fast = false;
     mi_mfma_plan plan{};
-    if (x->mode != MI_MODE_EXACT && x->dtype == MI_DTYPE_BF16 && x->metric == MI_METRIC_IP &&
-        mi_mfma_supported(x->d_pad, k) && mi_mfma_make_plan(n, x->d_pad, nq, k, &plan) == MI_OK)
+    if (x->mode != MI_MODE_EXACT && x->d_pad_scan != 0 && mi_mfma_supported(x->d_pad_scan, k) &&
+        mi_mfma_make_plan(n, x->d_pad_scan, nq, k, &plan) == MI_OK)
         fast = true;
     if (x->mode == MI_MODE_FAST && !fast) {
-        mi_set_error("search: MI_MODE_FAST requested but the MFMA path does not cover this index (dtype=%d metric=%d d_pad=%d n=%lld k=%d)",
-                     x->dtype, x->metric, x->d_pad, (long long)n, k);
+        mi_set_error("search: MI_MODE_FAST requested but the MFMA path does not cover this index (dtype=%d metric=%d d=%d n=%lld k=%d)",
+                     x->dtype, x->metric, x->d, (long long)n, k);
         return MI_ERR_UNSUPPORTED;
     }
+    const bool bf16_index = x->dtype == MI_DTYPE_BF16;
 
     const int nq_alloc = fast ? plan.nq_pad : nq;
     MI_TRY(x->q_canon.ensure((size_t)nq_alloc * x->d_pad * sizeof(float)));
     MI_TRY(x->qq.ensure((size_t)nq_alloc * sizeof(float)));
     uint16_t* qb = nullptr;
     if (fast) {
-        MI_TRY(x->q_bf16.ensure((size_t)plan.nq_pad * x->d_pad * sizeof(uint16_t)));
+        MI_TRY(x->q_bf16.ensure((size_t)plan.nq_pad * x->d_pad_scan * sizeof(uint16_t)));
         qb = x->q_bf16.as<uint16_t>();
         if (plan.nq_pad > nq)
-            MI_HIP(hipMemsetAsync(qb + (size_t)nq * x->d_pad, 0, (size_t)(plan.nq_pad - nq) * x->d_pad * sizeof(uint16_t), st));
+            MI_HIP(hipMemsetAsync(qb + (size_t)nq * x->d_pad_scan, 0, (size_t)(plan.nq_pad - nq) * x->d_pad_scan * sizeof(uint16_t), st));
     }
-    MI_TRY(mi_launch_prep_queries(st, q_dev, nq, x->d, x->d_pad, x->dtype, x->q_canon.as<float>(), qb, x->qq.as<float>()));
+    MI_TRY(mi_launch_prep_queries(st, q_dev, nq, x->d, x->d_pad, bf16_index ? 1 : 0, x->q_canon.as<float>(),
+                                  x->d_pad_scan, qb, x->qq.as<float>()));
 
     x->st_queries += nq;
     x->st_rows = n;
@@ -453,23 +477,47 @@ static int search_dev_locked(mi_index* x, int64_t nq64, const float* q_dev, int 
         return MI_OK;
     }
 
-    // ---- MFMA scan + certificate
+    // ---- MFMA scan + finish + certificate
     x->last_kind = 1;
+    const uint16_t* scan_rows = (const uint16_t*)x->rows;
+    if (!bf16_index) {
+        MI_TRY(ensure_shadow(x, st));
+        scan_rows = x->shadow.as<uint16_t>();
+    }
+    float eps_acc = 0.0f, eps_round = 0.0f;
+    mi_mfma_eps(x->d_pad_scan, !bf16_index, &eps_acc, &eps_round);
     MI_TRY(x->lists.ensure(plan.list_bytes));
     MI_TRY(x->cnts.ensure(plan.cnt_bytes));
     MI_TRY(x->thrs.ensure(plan.thr_bytes));
-    MI_TRY(x->fail.ensure((size_t)(nq + 64) * sizeof(int32_t)));
+    MI_TRY(x->gthr.ensure((size_t)plan.nq_pad * sizeof(uint32_t)));
+    MI_HIP(hipMemsetAsync(x->gthr.p, 0, (size_t)plan.nq_pad * sizeof(uint32_t), st));
+    // fail: [0] = count, [64 ..) = list of failed queries, then the per-query overflow flags
+    MI_TRY(x->fail.ensure((size_t)(2 * (size_t)nq + 64) * sizeof(int32_t)));
     int32_t* fail_count = x->fail.as<int32_t>();
     int32_t* fail_list = fail_count + 64;
+    int32_t* over_flags = fail_list + nq;
     MI_HIP(hipMemsetAsync(fail_count, 0, 256, st));
+    MI_HIP(hipMemsetAsync(over_flags, 0, (size_t)nq * sizeof(int32_t), st));
     MI_TRY(ev_begin(x, st));
-    MI_TRY(mi_launch_mfma_scan(st, &plan, x->metric, (const uint16_t*)x->rows, x->xx, n, x->d_pad, qb, nq,
-                               x->lists.as<uint64_t>(), x->cnts.as<int32_t>(), x->thrs.as<float>()));
+    MI_TRY(mi_launch_mfma_scan(st, &plan, x->metric, scan_rows, x->xx, n, x->d_pad_scan, qb, nq,
+                               x->lists.as<uint64_t>(), x->cnts.as<int32_t>(), x->thrs.as<float>(), x->gthr.as<uint32_t>()));
     MI_TRY(ev_end(x, st));
-    MI_TRY(mi_launch_mfma_finish(st, &plan, x->metric, (const uint16_t*)x->rows, x->xx, x->max_xx, n, x->d_pad,
-                                 x->q_canon.as<float>(), x->qq.as<float>(), nq, k, x->id_base,
-                                 x->lists.as<uint64_t>(), x->cnts.as<int32_t>(), x->thrs.as<float>(),
-                                 out_s, out_i, fail_list, fail_count));
+    if (plan.ngroups == 1) {
+        MI_TRY(mi_launch_mfma_finish(st, &plan, x->metric, x->rows, x->dtype, x->xx, x->max_xx, x->d_pad, eps_acc, eps_round,
+                                     x->q_canon.as<float>(), x->qq.as<float>(), nq, k, x->id_base,
+                                     x->lists.as<uint64_t>(), x->cnts.as<int32_t>(), out_s, out_i, k, over_flags));
+    } else {
+        const int64_t m = (int64_t)plan.ngroups * k;
+        MI_TRY(x->part_s.ensure((size_t)nq * m * sizeof(float)));
+        MI_TRY(x->part_i.ensure((size_t)nq * m * sizeof(int64_t)));
+        MI_TRY(mi_launch_mfma_finish(st, &plan, x->metric, x->rows, x->dtype, x->xx, x->max_xx, x->d_pad, eps_acc, eps_round,
+                                     x->q_canon.as<float>(), x->qq.as<float>(), nq, k, x->id_base,
+                                     x->lists.as<uint64_t>(), x->cnts.as<int32_t>(),
+                                     x->part_s.as<float>(), x->part_i.as<int64_t>(), m, over_flags));
+        MI_TRY(mi_launch_merge(st, x->metric, nq, (int)m, x->part_s.as<float>(), x->part_i.as<int64_t>(), m, k, out_s, out_i, k));
+    }
+    MI_TRY(mi_launch_mfma_certify(st, &plan, x->metric, nq, k, eps_acc, eps_round, x->qq.as<float>(), x->max_xx,
+                                  x->cnts.as<int32_t>(), x->thrs.as<float>(), out_s, out_i, over_flags, fail_list, fail_count));
     int32_t nfail = 0;
     MI_HIP(hipMemcpyAsync(&nfail, fail_count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     MI_HIP(hipStreamSynchronize(st));

@@ -7,7 +7,7 @@
 // One thread per output element pair is plenty: mi_index_add is bounded by PCIe, and the
 // bench corpus is produced by synth_kernel below.
 template <typename SRC, typename DST>
-__global__ __launch_bounds__(256) void ingest_kernel(const SRC* __restrict__ src, DST* __restrict__ dst,
+__global__ __launch_bounds__(256) void ingest_kernel(const SRC* __restrict__ src, int64_t src_pitch, DST* __restrict__ dst,
                                                      int64_t n, int d, int d_pad)
 {
     const int64_t total = n * (int64_t)d_pad;
@@ -16,28 +16,28 @@ __global__ __launch_bounds__(256) void ingest_kernel(const SRC* __restrict__ src
         const int c = (int)(i - r * d_pad);
         float v = 0.0f;
         if (c < d) {
-            if constexpr (sizeof(SRC) == 4) v = (float)src[r * d + c];
-            else v = mi_bf16_to_f32((uint16_t)src[r * d + c]);
+            if constexpr (sizeof(SRC) == 4) v = (float)src[r * src_pitch + c];
+            else v = mi_bf16_to_f32((uint16_t)src[r * src_pitch + c]);
         }
         if constexpr (sizeof(DST) == 4) dst[i] = v;
         else dst[i] = mi_f32_to_bf16(v);
     }
 }
 
-int mi_launch_ingest(hipStream_t st, const void* src, int src_dtype, int64_t n, int d, int d_pad,
+int mi_launch_ingest(hipStream_t st, const void* src, int src_dtype, int64_t src_pitch, int64_t n, int d, int d_pad,
                      int dst_dtype, void* dst)
 {
     if (n == 0) return MI_OK;
     const int64_t total = n * (int64_t)d_pad;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     if (src_dtype == MI_DTYPE_F32 && dst_dtype == MI_DTYPE_F32)
-        ingest_kernel<float, float><<<grid, 256, 0, st>>>((const float*)src, (float*)dst, n, d, d_pad);
+        ingest_kernel<float, float><<<grid, 256, 0, st>>>((const float*)src, src_pitch, (float*)dst, n, d, d_pad);
     else if (src_dtype == MI_DTYPE_F32 && dst_dtype == MI_DTYPE_BF16)
-        ingest_kernel<float, uint16_t><<<grid, 256, 0, st>>>((const float*)src, (uint16_t*)dst, n, d, d_pad);
+        ingest_kernel<float, uint16_t><<<grid, 256, 0, st>>>((const float*)src, src_pitch, (uint16_t*)dst, n, d, d_pad);
     else if (src_dtype == MI_DTYPE_BF16 && dst_dtype == MI_DTYPE_BF16)
-        ingest_kernel<uint16_t, uint16_t><<<grid, 256, 0, st>>>((const uint16_t*)src, (uint16_t*)dst, n, d, d_pad);
+        ingest_kernel<uint16_t, uint16_t><<<grid, 256, 0, st>>>((const uint16_t*)src, src_pitch, (uint16_t*)dst, n, d, d_pad);
     else
-        ingest_kernel<uint16_t, float><<<grid, 256, 0, st>>>((const uint16_t*)src, (float*)dst, n, d, d_pad);
+        ingest_kernel<uint16_t, float><<<grid, 256, 0, st>>>((const uint16_t*)src, src_pitch, (float*)dst, n, d, d_pad);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
@@ -183,41 +183,40 @@ int mi_launch_synth(hipStream_t st, void* dst, int dtype, int64_t n, int d, int 
 }
 
 // ---------------------------------------------------------------- query preparation
-// q_canon [nq][d_pad] fp32 (bf16-rounded values for a BF16 index, zero padded), optional
-// q_bf16 [nq][d_pad] bf16 bits, qq[q] = canonical dot(q,q).  One wave per query; the chain
-// for qq is continued by lane 0 only (nq * d fmas in total: negligible).
-__global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int64_t nq, int d, int d_pad,
-                                                           int dtype, float* __restrict__ q_canon,
+// q_canon [nq][d_pad_c] fp32 (bf16-rounded values when round_canon, zero padded), optional
+// q_bf16 [nq][d_pad_s] bf16 bits (always rounded), qq[q] = canonical dot(q,q) of the q_canon
+// values.  One wave per query; the chain for qq is continued by lane 0 only (nq * d fmas in
+// total: negligible).
+__global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int64_t nq, int d, int d_pad_c,
+                                                           int round_canon, float* __restrict__ q_canon, int d_pad_s,
                                                            uint16_t* __restrict__ q_bf16, float* __restrict__ qq)
 {
     const int lane = threadIdx.x & 63;
     const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= nq) return;
-    for (int k = lane; k < d_pad; k += 64) {
-        float v = (k < d) ? q[qi * d + k] : 0.0f;
-        if (dtype == MI_DTYPE_BF16) {
-            const uint16_t h = mi_f32_to_bf16(v);
-            v = mi_bf16_to_f32(h);
-            if (q_bf16) q_bf16[qi * d_pad + k] = h;
-        }
-        q_canon[qi * d_pad + k] = v;
+    const int kmax = d_pad_c > d_pad_s ? d_pad_c : d_pad_s;
+    for (int k = lane; k < kmax; k += 64) {
+        const float v = (k < d) ? q[qi * d + k] : 0.0f;
+        const uint16_t hb = mi_f32_to_bf16(v);
+        if (q_bf16 && k < d_pad_s) q_bf16[qi * d_pad_s + k] = hb;
+        if (k < d_pad_c) q_canon[qi * d_pad_c + k] = round_canon ? mi_bf16_to_f32(hb) : v;
     }
     if (lane == 0) {
         float acc = 0.0f;
         for (int k = 0; k < d; ++k) {
             float v = q[qi * d + k];
-            if (dtype == MI_DTYPE_BF16) v = mi_bf16_to_f32(mi_f32_to_bf16(v));
+            if (round_canon) v = mi_bf16_to_f32(mi_f32_to_bf16(v));
             acc = __builtin_fmaf(v, v, acc);
         }
         qq[qi] = acc;
     }
 }
 
-int mi_launch_prep_queries(hipStream_t st, const float* q, int64_t nq, int d, int d_pad, int dtype,
-                           float* q_canon, uint16_t* q_bf16, float* qq)
+int mi_launch_prep_queries(hipStream_t st, const float* q, int64_t nq, int d, int d_pad_c, int round_canon,
+                           float* q_canon, int d_pad_s, uint16_t* q_bf16, float* qq)
 {
     if (nq == 0) return MI_OK;
-    prep_queries_kernel<<<(unsigned)((nq + 3) / 4), 256, 0, st>>>(q, nq, d, d_pad, dtype, q_canon, q_bf16, qq);
+    prep_queries_kernel<<<(unsigned)((nq + 3) / 4), 256, 0, st>>>(q, nq, d, d_pad_c, round_canon, q_canon, d_pad_s, q_bf16, qq);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }

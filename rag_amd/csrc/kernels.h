@@ -7,14 +7,17 @@ int mi_ctx_device(mi_ctx* ctx);
 hipStream_t mi_ctx_stream(mi_ctx* ctx);
 
 // ---- ingest / synthetic data (ingest.hip)
-int mi_launch_ingest(hipStream_t st, const void* src, int src_dtype, int64_t n, int d, int d_pad,
+// dst[r][0..d_pad) <- src[r][0..d) zero padded; src rows are src_pitch elements apart.
+int mi_launch_ingest(hipStream_t st, const void* src, int src_dtype, int64_t src_pitch, int64_t n, int d, int d_pad,
                      int dst_dtype, void* dst);
 int mi_launch_row_norms(hipStream_t st, const void* rows, int dtype, int64_t n, int d_pad,
                         float* xx, float* max_xx);
 int mi_launch_synth(hipStream_t st, void* dst, int dtype, int64_t n, int d, int d_pad,
                     uint64_t seed, int64_t row0, int normalize);
-int mi_launch_prep_queries(hipStream_t st, const float* q, int64_t nq, int d, int d_pad, int dtype,
-                           float* q_canon, uint16_t* q_bf16, float* qq);
+// q_canon [nq][d_pad_c] fp32 (values rounded to bf16 first when round_canon), qq = canonical
+// dot(q,q) of those values; optional q_bf16 [nq][d_pad_s] = the bf16-rounded queries.
+int mi_launch_prep_queries(hipStream_t st, const float* q, int64_t nq, int d, int d_pad_c, int round_canon,
+                           float* q_canon, int d_pad_s, uint16_t* q_bf16, float* qq);
 int mi_launch_export_rows(hipStream_t st, const void* rows, int dtype, int64_t n, int d, int d_pad,
                           float* out);
 
@@ -46,20 +49,33 @@ struct mi_mfma_plan {
     int kprime;        // candidates kept per (slice, query)
     int cap;           // list capacity per (slice, query)
     int nslices;       // row slices
+    int ngroups;       // slice groups of the finish kernel (each <= spg slices)
+    int spg;           // slices per group
     int64_t slice_rows;// rows per slice (multiple of the tile height)
     int nq_pad;        // queries padded to the query tile
     size_t list_bytes, cnt_bytes, thr_bytes;
 };
 bool mi_mfma_supported(int d_pad, int k);
+// Row pitch (elements) the scan streams for dimension d: 128 / 384 / 768, or 0 (unsupported).
+int  mi_mfma_pitch(int d);
 int  mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* plan);
+// Relative error terms of the phase-1 score (see mf_err_bound in search_mfma.hip).
+void mi_mfma_eps(int d_pad_scan, bool rounded_shadow, float* eps_acc, float* eps_round);
 // Phase 1: bf16 MFMA scan + threshold filter -> per-(slice,query) candidate lists.
+// rows: bf16 [n][d_pad]; xx: canonical squared norms (L2 only).
 int  mi_launch_mfma_scan(hipStream_t st, const mi_mfma_plan* p, int metric, const uint16_t* rows,
                          const float* xx, int64_t n, int d_pad, const uint16_t* q_bf16, int64_t nq,
-                         uint64_t* lists, int32_t* cnts, float* thrs);
-// Phase 2: canonical re-score of every candidate, exact top-k, certificate.
-// fail_flags[q] = 1 where the certificate does not hold; *fail_count accumulates them.
-int  mi_launch_mfma_finish(hipStream_t st, const mi_mfma_plan* p, int metric, const uint16_t* rows,
-                           const float* xx, const float* max_xx, int64_t n, int d_pad,
+                         uint64_t* lists, int32_t* cnts, float* thrs, uint32_t* gthr /* [nq_pad], zeroed */);
+// Phase 2: per (query, slice group): prefilter by MFMA score, canonical re-score from the
+// canonical rows (canon_dtype, pitch d_pad), exact top-k at out[q * out_stride + g * k + j].
+// over_flags[q] = 1 where a group had more near-ties than it can sort.
+int  mi_launch_mfma_finish(hipStream_t st, const mi_mfma_plan* p, int metric, const void* canon_rows, int canon_dtype,
+                           const float* xx, const float* max_xx, int d_pad, float eps_acc, float eps_round,
                            const float* q_canon, const float* qq, int64_t nq, int k, int64_t id_base,
-                           const uint64_t* lists, const int32_t* cnts, const float* thrs,
-                           float* out_s, int64_t* out_i, int32_t* fail_list, int32_t* fail_count);
+                           const uint64_t* lists, const int32_t* cnts,
+                           float* out_s, int64_t* out_i, int64_t out_stride, int32_t* over_flags);
+// Phase 3: certificate on the final list (stride k); failing queries are appended to fail_list.
+int  mi_launch_mfma_certify(hipStream_t st, const mi_mfma_plan* p, int metric, int64_t nq, int k, float eps_acc, float eps_round,
+                            const float* qq, const float* max_xx, const int32_t* cnts, const float* thrs,
+                            const float* out_s, const int64_t* out_i, const int32_t* over_flags,
+                            int32_t* fail_list, int32_t* fail_count);

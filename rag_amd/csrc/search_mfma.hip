@@ -1,30 +1,42 @@
-// search_mfma.hip — the fast flat-search path for a BF16 index on gfx950 (MI355X):
+// search_mfma.hip — the fast flat-search path on gfx950 (MI355X), for BF16 indexes and (through
+// a bf16 shadow copy of the rows) F32 indexes, IP and L2 metrics:
 //
 //   phase 1  mfma_scan_kernel    bf16 MFMA scoring of a query tile against a streamed row
 //                                slice, with a per-query running threshold: only scores above
 //                                the slice's current K'-th best leave the accumulators.
-//   phase 2  mfma_finish_kernel  per query: re-score every surviving candidate in the canonical
-//                                fp32 fmaf order, sort by (score, id), and CERTIFY that no
-//                                row that was filtered out can belong to the top-k.
+//   phase 2  mfma_finish_kernel  per (query, slice group): pick the candidates that can still be
+//                                in the top-k from their MFMA scores, re-score those in the
+//                                canonical fp32 fmaf order, sort by (score, id).
+//            (merge_kernel of search_exact.hip joins the slice groups)
+//   phase 3  mfma_certify_kernel per query: CERTIFY that no row that was filtered out can belong
+//                                to the top-k; otherwise the query is re-run on the exact path.
 //
-// The MFMA accumulation order is not the canonical order, so phase-1 scores v~ are only used
-// to discard: every discarded row satisfies v~ <= thr (per slice), hence its canonical score
-// is <= max_slices(thr) + E, where E bounds |v~ - canonical| (both are fp32 accumulations of
-// the same exact products; E = eps_rel * |q| * max|x|, eps_rel = 4 * d * 2^-24).  If the k-th
-// best canonical score among the candidates is strictly above that bound the answer is
-// provably the exact top-k; otherwise the query is re-run on the exact path
-// (search_exact.hip).  Replaces faiss IndexFlat::search (advanced_rag.py:296).
+// The MFMA accumulation order is not the canonical order (and for an F32 index the shadow rows
+// are rounded), so phase-1 scores v~ are only used to discard.  With E a bound on
+// |v~ - canonical| (mf_err_bound: 4 d 2^-24 relative for the accumulation order, plus 2^-8 |q||x|
+// for a rounded shadow):
+//   * every row dropped in phase 1 has v~ <= thr(slice), hence canonical <= max_slices(thr) + E;
+//   * every candidate dropped in phase 2 has v~ < T_k - 2E where T_k is the k-th largest v~ of
+//     its group, hence k candidates of the group are strictly better in canonical order.
+// If the k-th best canonical score of the final list is strictly above max(thr) + E the list is
+// provably the exact top-k.  L2 uses v = dot - xx/2 (the accumulators start at -xx/2), which
+// orders rows like the negated distance.  Replaces faiss IndexFlat::search (advanced_rag.py:296).
 //
 // Data movement (d = 384: NKB = 3 k-blocks of 128 elements):
 //   * queries are register-stationary: each wave keeps the B fragments of its 32 queries x d
 //     (96 VGPRs at d = 384) for the whole kernel.  d <= 384: 8 waves per workgroup (two per
 //     SIMD, 256 registers each, 256 queries per workgroup) so one wave's LDS reads hide under
-//     its partner's MFMAs; d = 768: 4 waves, one per SIMD, 512-register budget.
+//     its partner's MFMAs; d = 768: 4 waves, one per SIMD, 512-register budget.  Waves whose 32
+//     queries are all padding only help with the loads.
 //   * corpus rows stream HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) in units of
-//     128 rows x 256 B, double buffered, each 256-B row segment XOR-swizzled by (row & 15) on
-//     the SOURCE side so the ds_read_b128 A-fragment reads are bank-conflict free.
+//     128 rows x 256 B through a ring of MF_NST buffers: MF_PD units are in flight while one is
+//     consumed, retired by counted s_waitcnt vmcnt(N) + a raw s_barrier (MF_PD = 1, 2 and 3
+//     measured within 2 % of each other in every regime; 1 keeps the indexing compile-time).
+//     Each 256-B row segment is XOR-swizzled by (row & 15) on the SOURCE side so the
+//     ds_read_b128 A-fragment reads are bank-conflict free.
 //   * workgroups that scan the same row slice carry the same (blockIdx % 8) so they share an
 //     XCD's L2: a slice is fetched from HBM once per XCD pass, not once per query tile.
+#include <stdlib.h>
 #include "kernels.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -34,7 +46,14 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 #define MF_TILE_R 128
 #define MF_STAGE_BYTES (MF_TILE_R * 256)
-#define MF_PH2_MAX 8192
+#define MF_PD 1                                    // LDS-DMA prefetch distance in units (1..3 measured equal)
+#define MF_NST (MF_PD + 1)                         // ring depth (units): MF_PD in flight + one being consumed
+#define MF_XXB 4                                   // ring depth of the per-tile xx / threshold buffers
+#define MF_XX_OFF (MF_NST * MF_STAGE_BYTES)
+#define MF_GT_OFF (MF_XX_OFF + MF_XXB * MF_TILE_R * 4)    // shared-threshold words: [MF_XXB][waves][64] u32
+#define MF_LDS_BYTES (MF_GT_OFF + MF_XXB * 8 * 256)
+#define MF_PH2_MAX 8192                            // candidate entries per (query, group) in LDS
+#define MF_SORT_MAX 1024                           // survivors re-scored and sorted per (query, group)
 #define MF_MIN_ROWS 32768
 
 __host__ __device__ constexpr int mf_cap(int kp) { return 2 * kp + 32; }
@@ -51,19 +70,31 @@ __device__ __forceinline__ void lds_read4(bf16x8 (&a)[4], unsigned addr)
                  : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]) : "v"(addr));
 }
 
+// Waits until at most `units` whole units (PPW LDS-DMA pieces each) of this wave are in flight.
+// Younger stores / loads of the filter only make the wait stricter (vmcnt counts in issue order).
+template <int PPW>
+__device__ __forceinline__ void wait_units(int units)
+{
+    static_assert(PPW * 2 <= 63, "vmcnt immediate");
+    if (units >= 2) { if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory"); }
+    else if (units == 1) { if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
 // ---------------------------------------------------------------- phase 1
-template <int NKB, int KP>
+template <int NKB, int KP, bool L2>
 __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
-    const uint16_t* __restrict__ rows, int64_t n, int pitch_bytes,
-    const uint16_t* __restrict__ q_bf16, int nq_pad, int nqt, int64_t slice_rows,
-    uint64_t* __restrict__ lists, int32_t* __restrict__ cnts, float* __restrict__ thrs)
+    const uint16_t* __restrict__ rows, const float* __restrict__ xx, int64_t n, int pitch_bytes,
+    const uint16_t* __restrict__ q_bf16, int nq, int nq_pad, int nqt, int64_t slice_rows,
+    uint64_t* __restrict__ lists, int32_t* __restrict__ cnts, float* __restrict__ thrs, uint32_t* __restrict__ gthr)
 {
     constexpr int WAVES = mf_waves(NKB);
     constexpr int PPW = 32 / WAVES;                   // 1-KiB LDS-DMA pieces per wave per unit
     constexpr int CAP = mf_cap(KP);
     constexpr int EPL = (CAP + 63) / 64;
     constexpr int KS = NKB * 8;                       // 16-wide k-steps per row
-    __shared__ __attribute__((aligned(1024))) char lds[2 * MF_STAGE_BYTES];
+    static_assert((MF_NST & (MF_NST - 1)) == 0 && MF_PD >= 1 && MF_PD <= 3, "ring of 2 or 4 buffers");
+    __shared__ __attribute__((aligned(1024))) char lds[MF_LDS_BYTES];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -78,19 +109,23 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
 
     const int d_pad = pitch_bytes >> 1;
     const int64_t qglob = (int64_t)qt * (32 * WAVES) + wave * 32 + col;   // this lane's query
+    const bool active = (int64_t)qt * (32 * WAVES) + wave * 32 < nq;      // wave-uniform
 
     // ---- B fragments: lane (col, h) holds query qglob, dims [16 s + 8 h, +8)
     bf16x8 bq[KS];
+    if (active) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const uint4 v = *reinterpret_cast<const uint4*>(q_bf16 + qglob * d_pad + 16 * s + 8 * h);
-        bq[s] = __builtin_bit_cast(bf16x8, v);
+        for (int s = 0; s < KS; ++s) {
+            const uint4 v = *reinterpret_cast<const uint4*>(q_bf16 + qglob * d_pad + 16 * s + 8 * h);
+            bq[s] = __builtin_bit_cast(bf16x8, v);
+        }
     }
 
     const int64_t row_begin = (int64_t)slice * slice_rows;
     int64_t row_end = row_begin + slice_rows;
     if (row_end > n) row_end = n;
     const int ntiles = (row_begin < row_end) ? (int)((row_end - row_begin + MF_TILE_R - 1) / MF_TILE_R) : 0;
+    const int nunits = ntiles * NKB;
 
     // ---- LDS-DMA geometry: wave w issues pieces p = PPW w + i, 4 rows x 256 B each.
     // LDS is lane-linear (row 4p + lane/16, slot lane%16); the lane fetches the 16-B chunk that
@@ -103,8 +138,28 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     const char* rows_b = reinterpret_cast<const char*>(rows);
     const int64_t last_row = n - 1;
 
+    // unit u = (tile, kb) lives in ring buffer u & 3; its tile's xx in xx buffer tile & 3
+    // gthr[q]: the best threshold any workgroup has published for query q (orderable word, 0 =
+    // none yet).  Any slice's K'-th best is a lower bound of the global K'-th best, so every
+    // workgroup may filter with it; a stale value is only a weaker, still valid, threshold.  It
+    // arrives by LDS-DMA (sc1: past this CU's L1) with the tile's first unit.
+    const uint32_t* gsrc = gthr + (qglob - col) + (lane & 31);
     auto issue_unit = [&](int tile, int kb, int buf) {
         const int64_t trow0 = row_begin + (int64_t)tile * MF_TILE_R;
+        if (kb == 0)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc,
+                (lds_ptr_t)(lds + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256), 4, 0, 16);
+        if constexpr (L2) {
+            if (kb == 0 && wave == 0) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    int64_t r = trow0 + 64 * half + lane;
+                    if (r > last_row) r = last_row;
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xx + r),
+                        (lds_ptr_t)(lds + MF_XX_OFF + (tile & (MF_XXB - 1)) * (MF_TILE_R * 4) + half * 256), 4, 0, 0);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int p = wave * PPW + i;                 // PPW is 4 or 8: p & 3 == i & 3
@@ -115,6 +170,9 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                 (lds_ptr_t)(lds + buf * MF_STAGE_BYTES + p * 1024), 16, 0, 0);
         }
     };
+    auto issue_linear = [&](int u) {                      // u < nunits
+        issue_unit(u / NKB, u % NKB, u & (MF_NST - 1));
+    };
 
     // ---- per-lane filter state, replicated in lanes (col) and (col + 32)
     float thr = -__builtin_inff();
@@ -122,60 +180,87 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     uint64_t* const list = lists + ((int64_t)slice * nq_pad + qglob) * CAP;
 
     f32x16 acc[4];
+    auto init_acc = [&](int tile) {
+        if constexpr (L2) {
+            const float* xl = reinterpret_cast<const float*>(lds + MF_XX_OFF + (tile & (MF_XXB - 1)) * (MF_TILE_R * 4));
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[m][i] = 0.0f;
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = *reinterpret_cast<const float4*>(xl + 32 * m + 8 * g + 4 * h);
+                    acc[m][4 * g + 0] = -0.5f * v.x; acc[m][4 * g + 1] = -0.5f * v.y;
+                    acc[m][4 * g + 2] = -0.5f * v.z; acc[m][4 * g + 3] = -0.5f * v.w;
+                }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][i] = 0.0f;
+        }
+    };
 
     // A-fragment read address: row (32 m + col), chunk (2 s + h) ^ (row & 15)
     const int a_row_off = col * 256;
     const int a_lo4 = lane & 15;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
-    if (ntiles > 0) {
-        issue_unit(0, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- prologue: put MF_PD units in flight, retire unit 0
+#pragma unroll
+    for (int u0 = 0; u0 < MF_PD; ++u0)
+        if (u0 < nunits) issue_linear(u0);
+    if (nunits > 0) {
+        const int younger = (nunits - 1 < MF_PD - 1) ? nunits - 1 : MF_PD - 1;
+        wait_units<PPW>(younger);
         __builtin_amdgcn_s_barrier();
+        if (active) init_acc(0);
     }
 
     int u = 0;
     for (int tile = 0; tile < ntiles; ++tile) {
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb, ++u) {
-            const int buf = u & 1;
-            {   // prefetch the next unit into the other buffer (everyone left it at the last barrier)
-                const int ntile = (kb == NKB - 1) ? tile + 1 : tile;
-                const int nkb = (kb == NKB - 1) ? 0 : kb + 1;
-                if (ntile < ntiles) issue_unit(ntile, nkb, buf ^ 1);
-            }
-            // A fragments are read one k-step ahead of the MFMAs that consume them.  The reads
-            // are inline asm so hipcc cannot sink each one next to its use (it serialises
-            // ds_read -> wait -> MFMA otherwise); LDS returns in order, so with the 4 reads of
-            // step s+1 just issued, lgkmcnt(4) means the 4 reads of step s have landed.
-            const unsigned cur = lds_base + buf * MF_STAGE_BYTES + a_row_off;
-            bf16x8 a[2][4];
-            lds_read4(a[0], cur + (((0 + h) ^ a_lo4) << 4));
+            const int buf = u & (MF_NST - 1);
+            // unit u + MF_PD goes into the buffer everyone left at the last barrier (unit u - 1's);
+            // its (tile, kb) is known at compile time relative to this one
+            if (u + MF_PD < nunits) issue_unit(tile + (kb + MF_PD) / NKB, (kb + MF_PD) % NKB, (u + MF_PD) & (MF_NST - 1));
+            if (active) {
+                // A fragments are read one k-step ahead of the MFMAs that consume them.  The reads
+                // are inline asm so hipcc cannot sink each one next to its use (it serialises
+                // ds_read -> wait -> MFMA otherwise); LDS returns in order, so with the 4 reads of
+                // step s+1 just issued, lgkmcnt(4) means the 4 reads of step s have landed.
+                const unsigned cur = lds_base + buf * MF_STAGE_BYTES + a_row_off;
+                bf16x8 a[2][4];
+                lds_read4(a[0], cur + (((0 + h) ^ a_lo4) << 4));
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (s < 7) {
-                    lds_read4(a[(s + 1) & 1], cur + (((2 * (s + 1) + h) ^ a_lo4) << 4));
-                    asm volatile("s_waitcnt lgkmcnt(4)"
-                                 : "+v"(a[s & 1][0]), "+v"(a[s & 1][1]), "+v"(a[s & 1][2]), "+v"(a[s & 1][3]));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(a[s & 1][0]), "+v"(a[s & 1][1]), "+v"(a[s & 1][2]), "+v"(a[s & 1][3]));
+                for (int s = 0; s < 8; ++s) {
+                    if (s < 7) {
+                        lds_read4(a[(s + 1) & 1], cur + (((2 * (s + 1) + h) ^ a_lo4) << 4));
+                        asm volatile("s_waitcnt lgkmcnt(4)"
+                                     : "+v"(a[s & 1][0]), "+v"(a[s & 1][1]), "+v"(a[s & 1][2]), "+v"(a[s & 1][3]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(a[s & 1][0]), "+v"(a[s & 1][1]), "+v"(a[s & 1][2]), "+v"(a[s & 1][3]));
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][m], bq[kb * 8 + s], acc[m], 0, 0, 0);
                 }
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][m], bq[kb * 8 + s], acc[m], 0, 0, 0);
             }
-            // my LDS reads of this buffer are retired and my DMA into the other one has landed
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // my LDS reads of this buffer are retired; my pieces of unit u + 1 have landed
+            {
+                const int rem = nunits - 2 - u;           // units younger than u + 1 that exist
+                wait_units<PPW>(rem < 0 ? 0 : (rem < MF_PD - 1 ? rem : MF_PD - 1));
+            }
             __builtin_amdgcn_s_barrier();
         }
+        if (!active) continue;
 
         // ---- filter: anything above the query's running threshold leaves the accumulators
         const int64_t trow0 = row_begin + (int64_t)tile * MF_TILE_R;
+        {
+            const uint32_t gw = *reinterpret_cast<const uint32_t*>(lds + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256 + col * 4);
+            if (gw != 0) thr = __builtin_fmaxf(thr, mi_unord_f32(gw));
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const f32x16 c = acc[m];
@@ -244,12 +329,18 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                         base_eq += __builtin_popcountll(m_eq);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    if (col == ql) { cnt = KP; thr = mi_unord_f32(T); }
+                    if (col == ql) {
+                        cnt = KP;
+                        const float tnew = mi_unord_f32(T);
+                        if (tnew > thr) {
+                            thr = tnew;
+                            if (h == 0) __hip_atomic_fetch_max(gthr + qglob, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][i] = 0.0f;
         }
+        if (tile + 1 < ntiles) init_acc(tile + 1);
     }
 
     if (h == 0) {
@@ -258,48 +349,35 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     }
 }
 
-// ---------------------------------------------------------------- phase 2
-__global__ __launch_bounds__(256) void mfma_finish_kernel(
-    int metric, const uint16_t* __restrict__ rows, const float* __restrict__ xx,
-    const float* __restrict__ max_xx, int64_t n, int d_pad, const float* __restrict__ q_canon,
-    const float* __restrict__ qq, int nq_pad, int k, int64_t id_base, int ns, int cap, float eps_rel,
-    const uint64_t* __restrict__ lists, const int32_t* __restrict__ cnts, const float* __restrict__ thrs,
-    float* __restrict__ out_s, int64_t* __restrict__ out_i, int32_t* __restrict__ fail_list,
-    int32_t* __restrict__ fail_count)
+// E: bound on |v~ - c| where v~ is the phase-1 score (MFMA accumulation, possibly of rounded
+// shadow rows) and c the canonical one in the same units (IP: dot; L2: (qq - dist) / 2).
+//   accumulation: both are fp32 sums of the same terms in different orders, |diff| <= eps_acc * sum|terms|,
+//                 sum|terms| <= |q||x| (+ xx/2 + qq/2 for L2, which also covers the rounding of the distance formula)
+//   rounding    : |q.x - q~.x~| <= eps_round * |q||x|  (bf16 shadow of an F32 index; 0 for a BF16 index)
+__device__ __forceinline__ float mf_err_bound(int metric, float qqv, float mx, float eps_acc, float eps_round)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                 // [MF_PH2_MAX]
-    float* qrow = reinterpret_cast<float*>(smem + MF_PH2_MAX * 8);      // [d_pad]
-    int* offs = reinterpret_cast<int*>(qrow + d_pad);                   // [ns + 1]
-    __shared__ float s_tmax;
+    const float qx = sqrtf(qqv * mx);
+    float E = (eps_acc + eps_round) * qx;
+    if (metric == MI_METRIC_L2) E += eps_acc * 0.5f * (qqv + mx);
+    return E;
+}
 
-    const int t = threadIdx.x;
-    const int64_t q = blockIdx.x;
-
-    if (t == 0) {
-        int o = 0;
-        float tm = -__builtin_inff();
-        for (int s = 0; s < ns; ++s) {
-            offs[s] = o;
-            o += cnts[(int64_t)s * nq_pad + q];
-            tm = __builtin_fmaxf(tm, thrs[(int64_t)s * nq_pad + q]);
-        }
-        offs[ns] = o;
-        s_tmax = tm;
-    }
-    for (int c = t; c < d_pad; c += 256) qrow[c] = q_canon[q * d_pad + c];
+// ---------------------------------------------------------------- phase 2
+__device__ __forceinline__ int block_sum_256(int v, int* red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();                       // red may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    const int total = offs[ns];
-    const float qqv = qq[q];
+    return red[0] + red[1] + red[2] + red[3];
+}
 
-    // canonical re-score of every candidate
-    for (int e = t; e < total; e += 256) {
-        int lo = 0, hi = ns;                 // slice with offs[s] <= e < offs[s+1]
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= e) lo = mid; else hi = mid; }
-        const uint64_t ent = lists[((int64_t)lo * nq_pad + q) * cap + (e - offs[lo])];
-        const uint32_t row = (uint32_t)ent;
-        const uint16_t* xr = rows + (int64_t)row * d_pad;
-        float acc = 0.0f;
+template <typename RT>
+__device__ __forceinline__ float canon_dot(const RT* __restrict__ xr, const float* __restrict__ qrow, int d_pad)
+{
+    float acc = 0.0f;
+    if constexpr (sizeof(RT) == 2) {
         for (int c = 0; c < d_pad; c += 8) {
             const uint4 v = *reinterpret_cast<const uint4*>(xr + c);
             const float4 q0 = *reinterpret_cast<const float4*>(qrow + c);
@@ -313,11 +391,103 @@ __global__ __launch_bounds__(256) void mfma_finish_kernel(
             acc = __builtin_fmaf(q1.z, __builtin_bit_cast(float, v.w << 16), acc);
             acc = __builtin_fmaf(q1.w, __builtin_bit_cast(float, v.w & 0xFFFF0000u), acc);
         }
-        const uint32_t rk = (metric == MI_METRIC_L2) ? mi_rank_l2(acc, qqv, xx[row]) : mi_rank_ip(acc);
+    } else {
+        for (int c = 0; c < d_pad; c += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            const float4 q0 = *reinterpret_cast<const float4*>(qrow + c);
+            acc = __builtin_fmaf(q0.x, v.x, acc);
+            acc = __builtin_fmaf(q0.y, v.y, acc);
+            acc = __builtin_fmaf(q0.z, v.z, acc);
+            acc = __builtin_fmaf(q0.w, v.w, acc);
+        }
+    }
+    return acc;
+}
+
+// grid (nq, ngroups).  rows: the CANONICAL rows (bf16 index: the bf16 rows; F32 index: the fp32
+// rows), pitch d_pad elements.  Output: the group's best k at out[q * out_stride + g * k + j].
+template <typename RT>
+__global__ __launch_bounds__(256) void mfma_finish_kernel(
+    int metric, const RT* __restrict__ rows, const float* __restrict__ xx, const float* __restrict__ max_xx,
+    int d_pad, const float* __restrict__ q_canon, const float* __restrict__ qq, int nq_pad, int k,
+    int64_t id_base, int ns, int spg, int cap, float eps_acc, float eps_round,
+    const uint64_t* __restrict__ lists, const int32_t* __restrict__ cnts,
+    float* __restrict__ out_s, int64_t* __restrict__ out_i, int64_t out_stride, int32_t* __restrict__ over_flags)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* ent = reinterpret_cast<uint64_t*>(smem);                              // [MF_PH2_MAX]
+    uint64_t* keys = ent + MF_PH2_MAX;                                              // [MF_SORT_MAX]
+    float* qrow = reinterpret_cast<float*>(keys + MF_SORT_MAX);                     // [d_pad]
+    int* offs = reinterpret_cast<int*>(qrow + d_pad);                               // [spg + 1]
+    __shared__ int red[4];
+    __shared__ int s_nsurv;
+
+    const int t = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    const int g = blockIdx.y;
+    const int s0 = g * spg;
+    const int s1 = (s0 + spg < ns) ? s0 + spg : ns;
+    const int nsl = s1 - s0;
+
+    if (t == 0) {
+        int o = 0;
+        for (int s = 0; s < nsl; ++s) { offs[s] = o; o += cnts[(int64_t)(s0 + s) * nq_pad + q]; }
+        offs[nsl] = o;
+        s_nsurv = 0;
+    }
+    for (int c = t; c < d_pad; c += 256) qrow[c] = q_canon[q * d_pad + c];
+    __syncthreads();
+    const int total = offs[nsl];                       // <= spg * cap <= MF_PH2_MAX
+    const float qqv = qq[q];
+
+    // ---- gather the group's candidate entries (MFMA score word << 32 | row)
+    for (int e = t; e < total; e += 256) {
+        int lo = 0, hi = nsl;                          // slice with offs[s] <= e < offs[s+1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= e) lo = mid; else hi = mid; }
+        ent[e] = lists[((int64_t)(s0 + lo) * nq_pad + q) * cap + (e - offs[lo])];
+    }
+    __syncthreads();
+
+    // ---- T_k = k-th largest MFMA score word (0 when total <= k: keep everything)
+    uint32_t T = 0;
+    if (total > k) {
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = T | (1u << bit);
+            int c = 0;
+            for (int e = t; e < total; e += 256) c += ((uint32_t)(ent[e] >> 32) >= cand) ? 1 : 0;
+            if (block_sum_256(c, red) >= k) T = cand;
+        }
+    }
+    // survivors: v~ >= T_k - 2E  (every other candidate has k strictly better ones in this group)
+    uint32_t Tlow = 0;
+    if (T != 0) {
+        const float E = mf_err_bound(metric, qqv, *max_xx, eps_acc, eps_round);
+        const float lowf = mi_unord_f32(T) - 2.0f * E;
+        Tlow = (lowf == lowf) ? mi_ord_f32(lowf) : 0u;
+    }
+    for (int e = t; e < total; e += 256) {
+        const uint64_t en = ent[e];
+        if ((uint32_t)(en >> 32) >= Tlow) {
+            const int pos = atomicAdd(&s_nsurv, 1);
+            if (pos < MF_SORT_MAX) keys[pos] = en;
+        }
+    }
+    __syncthreads();
+    int nsurv = s_nsurv;
+    if (nsurv > MF_SORT_MAX) {                           // too many near-ties: hand the query to the exact path
+        if (t == 0) over_flags[q] = 1;
+        nsurv = MF_SORT_MAX;
+    }
+
+    // ---- canonical re-score of the survivors
+    for (int e = t; e < nsurv; e += 256) {
+        const uint32_t row = (uint32_t)keys[e];
+        const float dot = canon_dot<RT>(rows + (int64_t)row * d_pad, qrow, d_pad);
+        const uint32_t rk = (metric == MI_METRIC_L2) ? mi_rank_l2(dot, qqv, xx[row]) : mi_rank_ip(dot);
         keys[e] = ((uint64_t)rk << 32) | (uint32_t)(~row);
     }
-    const int P = (total > 1) ? (1 << (32 - __builtin_clz(total - 1))) : 1;
-    for (int e = total + t; e < P; e += 256) keys[e] = 0;
+    const int P = (nsurv > 1) ? (1 << (32 - __builtin_clz(nsurv - 1))) : 1;
+    for (int e = nsurv + t; e < P; e += 256) keys[e] = 0;
     // sort descending (bitonic, LDS)
     for (int size = 2; size <= P; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -333,44 +503,66 @@ __global__ __launch_bounds__(256) void mfma_finish_kernel(
     }
     __syncthreads();
 
-    const int nsel = (total < k) ? total : k;
+    const int nsel = (nsurv < k) ? nsurv : k;
+    float* os = out_s + q * out_stride + (int64_t)g * k;
+    int64_t* oi = out_i + q * out_stride + (int64_t)g * k;
     for (int jj = t; jj < k; jj += 256) {
         if (jj < nsel) {
             const uint64_t key = keys[jj];
-            out_s[q * k + jj] = mi_score_from_rank(metric, (uint32_t)(key >> 32));
-            out_i[q * k + jj] = id_base + (int64_t)(uint32_t)(~(uint32_t)key);
+            os[jj] = mi_score_from_rank(metric, (uint32_t)(key >> 32));
+            oi[jj] = id_base + (int64_t)(uint32_t)(~(uint32_t)key);
         } else {
-            out_s[q * k + jj] = mi_pad_score(metric);
-            out_i[q * k + jj] = -1;
+            os[jj] = mi_pad_score(metric);
+            oi[jj] = -1;
         }
     }
+}
 
-    // certificate
-    if (t == 0) {
-        const float tmax = s_tmax;
-        bool ok;
-        if (tmax == -__builtin_inff()) {
-            ok = true;                                       // nothing was ever filtered out
-        } else if (total < k) {
-            ok = false;
+// ---------------------------------------------------------------- phase 3: certificate
+// One wave per query.  out_s/out_i: the final best-first list (stride k).
+__global__ __launch_bounds__(256) void mfma_certify_kernel(
+    int metric, int64_t nq, int nq_pad, int k, int ns, float eps_acc, float eps_round,
+    const float* __restrict__ qq, const float* __restrict__ max_xx,
+    const int32_t* __restrict__ cnts, const float* __restrict__ thrs,
+    const float* __restrict__ out_s, const int64_t* __restrict__ out_i,
+    const int32_t* __restrict__ over_flags, int32_t* __restrict__ fail_list, int32_t* __restrict__ fail_count)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    float tmax = -__builtin_inff();
+    int total = 0;
+    for (int s = lane; s < ns; s += 64) {
+        tmax = __builtin_fmaxf(tmax, thrs[(int64_t)s * nq_pad + q]);
+        total += cnts[(int64_t)s * nq_pad + q];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, off, 64));
+        total += __shfl_xor(total, off, 64);
+    }
+    if (lane != 0) return;
+    bool ok;
+    if (over_flags[q] != 0 || total < k || out_i[q * k + k - 1] < 0) {
+        ok = false;                                          // n >= MF_MIN_ROWS > k: rows went missing (NaN scores, overflow)
+    } else if (tmax == -__builtin_inff()) {
+        ok = true;                                           // nothing was ever filtered out in phase 1
+    } else {
+        const float qqv = qq[q];
+        const float ck = out_s[q * k + k - 1];
+        // x1.25: head-room for the fp32 evaluation of the bound itself
+        const float E = 1.25f * mf_err_bound(metric, qqv, *max_xx, eps_acc, eps_round);
+        if (metric == MI_METRIC_L2) {
+            // filtered rows have (dot~ - xx/2) <= tmax  =>  canonical dist >= qq - 2 (tmax + E)
+            ok = ck < qqv - 2.0f * (tmax + E);
         } else {
-            const float mx = *max_xx;
-            const float ck = mi_score_from_rank(metric, (uint32_t)(keys[k - 1] >> 32));
-            if (metric == MI_METRIC_L2) {
-                // filtered rows have (dot~ - xx/2) <= tmax  =>  true dist >= qq - 2 tmax - slack
-                const float mag = qqv + mx + 2.0f * sqrtf(qqv * mx);
-                const float bound = qqv - 2.0f * tmax - 4.0f * eps_rel * mag;
-                ok = ck < bound;
-            } else {
-                const float bound = tmax + eps_rel * sqrtf(qqv * mx);
-                ok = ck > bound;
-            }
-            if (!(ck == ck)) ok = false;
+            ok = ck > tmax + E;
         }
-        if (!ok) {
-            const int pos = atomicAdd(fail_count, 1);
-            fail_list[pos] = (int32_t)q;
-        }
+        if (!(ck == ck)) ok = false;
+    }
+    if (!ok) {
+        const int pos = atomicAdd(fail_count, 1);
+        fail_list[pos] = (int32_t)q;
     }
 }
 
@@ -393,22 +585,42 @@ static int pick_nkb(int d_pad)
 
 bool mi_mfma_supported(int d_pad, int k) { return pick_nkb(d_pad) != 0 && pick_kp(k) != 0; }
 
+// Row pitch (elements) of a bf16 matrix the scan can stream: 128 / 384 / 768, or 0.
+int mi_mfma_pitch(int d)
+{
+    const int p = mi_pad_dim(d);
+    if (p <= 128) return 128;
+    if (p <= 384) return 384;
+    if (p <= 768) return 768;
+    return 0;
+}
+
 int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* plan)
 {
     const int nkb = pick_nkb(d_pad), kp = pick_kp(k);
-    if (!nkb || !kp || n < MF_MIN_ROWS || n >= ((int64_t)1 << 32)) return MI_ERR_UNSUPPORTED;
+    if (!nkb || !kp || n < MF_MIN_ROWS || n >= ((int64_t)1 << 32) || k > MF_SORT_MAX / 2) return MI_ERR_UNSUPPORTED;
     const int qtile = 32 * mf_waves(nkb);
     const int cap = mf_cap(kp);
     const int64_t nqt = (nq + qtile - 1) / qtile;
-    int ns_max = (MF_PH2_MAX / cap) / 8 * 8;
+    const int spg_max = (MF_PH2_MAX / cap) / 8 * 8;               // slices whose lists fit one finish block
+    int gmax = 4096 / k;                                          // merge_kernel takes <= 4096 entries per query
+    if (gmax > 16) gmax = 16;
+    // >= ~1024 workgroups in the grid (four per CU over the launch), one slice per XCD at least
     int ns = (int)mi_round_up((1024 + nqt - 1) / nqt, 8);
-    if (ns > ns_max) ns = ns_max;
+    if (ns > spg_max * gmax) ns = spg_max * gmax;
     // at least ~32 tiles per slice so the running thresholds have time to tighten
     while (ns > 8 && n / ns < 32 * MF_TILE_R) ns -= 8;
     if (ns < 8) ns = 8;
+    if (const char* e = getenv("MI_MFMA_NS")) {
+        const int v = atoi(e) / 8 * 8;
+        if (v >= 8 && v <= spg_max * gmax && n / v >= MF_TILE_R) ns = v;
+    }
+    const int ngroups = (ns + spg_max - 1) / spg_max;
     plan->kprime = kp;
     plan->cap = cap;
     plan->nslices = ns;
+    plan->ngroups = ngroups;
+    plan->spg = (ns + ngroups - 1) / ngroups;
     plan->slice_rows = mi_round_up((n + ns - 1) / ns, MF_TILE_R);
     plan->nq_pad = (int)(nqt * qtile);
     plan->list_bytes = (size_t)ns * plan->nq_pad * cap * sizeof(uint64_t);
@@ -417,26 +629,28 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
     return MI_OK;
 }
 
-template <int NKB, int KP>
-static void launch_scan(hipStream_t st, const mi_mfma_plan* p, const uint16_t* rows, int64_t n, int d_pad,
-                        const uint16_t* q_bf16, uint64_t* lists, int32_t* cnts, float* thrs)
+template <int NKB, int KP, bool L2>
+static void launch_scan(hipStream_t st, const mi_mfma_plan* p, const uint16_t* rows, const float* xx, int64_t n,
+                        int d_pad, const uint16_t* q_bf16, int nq, uint64_t* lists, int32_t* cnts, float* thrs, uint32_t* gthr)
 {
     const int qtile = 32 * mf_waves(NKB);
     const int nqt = p->nq_pad / qtile;
     const unsigned grid = (unsigned)(nqt * p->nslices);
-    mfma_scan_kernel<NKB, KP><<<grid, 64 * mf_waves(NKB), 0, st>>>(rows, n, d_pad * 2, q_bf16, p->nq_pad, nqt,
-                                                     p->slice_rows, lists, cnts, thrs);
+    mfma_scan_kernel<NKB, KP, L2><<<grid, 64 * mf_waves(NKB), 0, st>>>(rows, xx, n, d_pad * 2, q_bf16, nq, p->nq_pad, nqt,
+                                                                       p->slice_rows, lists, cnts, thrs, gthr);
 }
 
 int mi_launch_mfma_scan(hipStream_t st, const mi_mfma_plan* p, int metric, const uint16_t* rows,
                         const float* xx, int64_t n, int d_pad, const uint16_t* q_bf16, int64_t nq,
-                        uint64_t* lists, int32_t* cnts, float* thrs)
+                        uint64_t* lists, int32_t* cnts, float* thrs, uint32_t* gthr)
 {
-    (void)xx; (void)nq;
-    if (metric != MI_METRIC_IP) { mi_set_error("mfma scan: L2 metric not built yet"); return MI_ERR_UNSUPPORTED; }
     const int nkb = pick_nkb(d_pad);
+    const bool l2 = metric == MI_METRIC_L2;
 #define MF_CASE(NKB_, KP_) \
-    if (nkb == NKB_ && p->kprime == KP_) { launch_scan<NKB_, KP_>(st, p, rows, n, d_pad, q_bf16, lists, cnts, thrs); MI_HIP(hipGetLastError()); return MI_OK; }
+    if (nkb == NKB_ && p->kprime == KP_) { \
+        if (l2) launch_scan<NKB_, KP_, true>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+        else launch_scan<NKB_, KP_, false>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+        MI_HIP(hipGetLastError()); return MI_OK; }
     MF_CASE(1, 16) MF_CASE(1, 32) MF_CASE(1, 128)
     MF_CASE(3, 16) MF_CASE(3, 32) MF_CASE(3, 128)
     MF_CASE(6, 16) MF_CASE(6, 32) MF_CASE(6, 128)
@@ -445,23 +659,49 @@ int mi_launch_mfma_scan(hipStream_t st, const mi_mfma_plan* p, int metric, const
     return MI_ERR_UNSUPPORTED;
 }
 
-int mi_launch_mfma_finish(hipStream_t st, const mi_mfma_plan* p, int metric, const uint16_t* rows,
-                          const float* xx, const float* max_xx, int64_t n, int d_pad,
+void mi_mfma_eps(int d_pad_scan, bool rounded_shadow, float* eps_acc, float* eps_round)
+{
+    *eps_acc = 4.0f * (float)d_pad_scan * 5.9604645e-8f;
+    // shadow rows and queries rounded to bf16: |q.x - q~.x~| <= (2^-9 + 2^-9 + 2^-18) sum|q_k x_k|
+    *eps_round = rounded_shadow ? 0.00390625f * 1.01f : 0.0f;
+}
+
+int mi_launch_mfma_finish(hipStream_t st, const mi_mfma_plan* p, int metric, const void* canon_rows, int canon_dtype,
+                          const float* xx, const float* max_xx, int d_pad, float eps_acc, float eps_round,
                           const float* q_canon, const float* qq, int64_t nq, int k, int64_t id_base,
-                          const uint64_t* lists, const int32_t* cnts, const float* thrs,
-                          float* out_s, int64_t* out_i, int32_t* fail_list, int32_t* fail_count)
+                          const uint64_t* lists, const int32_t* cnts,
+                          float* out_s, int64_t* out_i, int64_t out_stride, int32_t* over_flags)
 {
     if (nq <= 0) return MI_OK;
-    const size_t smem = (size_t)MF_PH2_MAX * 8 + (size_t)d_pad * 4 + (size_t)(p->nslices + 1) * 4;
+    const size_t smem = (size_t)MF_PH2_MAX * 8 + (size_t)MF_SORT_MAX * 8 + (size_t)d_pad * 4 + (size_t)(p->spg + 1) * 4;
+    if (smem > 150 * 1024) { mi_set_error("mfma finish: d_pad %d too large", d_pad); return MI_ERR_UNSUPPORTED; }
     static bool attr_set = false;
     if (!attr_set) {
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_finish_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_finish_kernel<uint16_t>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_finish_kernel<float>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    const float eps_rel = 4.0f * (float)d_pad * 5.9604645e-8f;
-    mfma_finish_kernel<<<(unsigned)nq, 256, smem, st>>>(metric, rows, xx, max_xx, n, d_pad, q_canon, qq,
-        p->nq_pad, k, id_base, p->nslices, p->cap, eps_rel, lists, cnts, thrs, out_s, out_i, fail_list, fail_count);
+    const dim3 grid((unsigned)nq, (unsigned)p->ngroups);
+    if (canon_dtype == MI_DTYPE_BF16)
+        mfma_finish_kernel<uint16_t><<<grid, 256, smem, st>>>(metric, (const uint16_t*)canon_rows, xx, max_xx, d_pad, q_canon, qq,
+            p->nq_pad, k, id_base, p->nslices, p->spg, p->cap, eps_acc, eps_round, lists, cnts, out_s, out_i, out_stride, over_flags);
+    else
+        mfma_finish_kernel<float><<<grid, 256, smem, st>>>(metric, (const float*)canon_rows, xx, max_xx, d_pad, q_canon, qq,
+            p->nq_pad, k, id_base, p->nslices, p->spg, p->cap, eps_acc, eps_round, lists, cnts, out_s, out_i, out_stride, over_flags);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_launch_mfma_certify(hipStream_t st, const mi_mfma_plan* p, int metric, int64_t nq, int k, float eps_acc, float eps_round,
+                           const float* qq, const float* max_xx, const int32_t* cnts, const float* thrs,
+                           const float* out_s, const int64_t* out_i, const int32_t* over_flags,
+                           int32_t* fail_list, int32_t* fail_count)
+{
+    if (nq <= 0) return MI_OK;
+    mfma_certify_kernel<<<(unsigned)((nq + 3) / 4), 256, 0, st>>>(metric, nq, p->nq_pad, k, p->nslices, eps_acc, eps_round, qq, max_xx,
+                                                                  cnts, thrs, out_s, out_i, over_flags, fail_list, fail_count);
     MI_HIP(hipGetLastError());
     return MI_OK;
 }

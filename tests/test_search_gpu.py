@@ -76,6 +76,66 @@ def test_mfma_path_matches_oracle(oracle_mod, n, d, nq, k):
     assert st["fast"] >= nq * 0.9, st          # random data: the certificate should nearly always hold
 
 
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("n,d,nq,k", [(40000, 384, 70, 10), (50000, 200, 9, 5), (45000, 768, 33, 100), (33000, 100, 3, 4)])
+def test_mfma_path_all_metrics_and_dtypes(oracle_mod, metric, dtype, n, d, nq, k):
+    """L2 runs on the MFMA path with the accumulators started at -xx/2; an F32 index filters on
+    its bf16 shadow and re-scores from the fp32 rows.  Rows are NOT unit norm here."""
+    from rag_amd.index import MODE_FAST
+    rng = np.random.default_rng(n + d + k + len(metric))
+    X = _unit(rng, n, d) * rng.uniform(0.5, 1.5, size=(n, 1)).astype(np.float32)
+    Q = _unit(rng, nq, d) * rng.uniform(0.5, 2.0, size=(nq, 1)).astype(np.float32)
+    idx = _check(oracle_mod, X, Q, k, metric, dtype, mode=MODE_FAST)
+    st = idx.stats()
+    assert st["fast"] + st["exact"] == nq
+    # a bf16 index certifies nearly always; the rounded shadow of an F32 index widens the bound
+    # (2^-8 |q||x|), which at this small n / few slices sends more queries to the exact path
+    assert st["fast"] >= nq * (0.8 if dtype == "bf16" else 0.0), st
+    print(f"certified {st['fast']}/{nq} ({metric}, {dtype}, n={n})")
+
+
+@pytest.mark.parametrize("metric,dtype", [("ip", "bf16"), ("l2", "bf16"), ("l2", "f32")])
+def test_mfma_many_slices_grouped_finish(oracle_mod, metric, dtype):
+    """Few queries over many rows: hundreds of row slices, several finish groups + merge."""
+    from rag_amd.index import FlatIndex, MODE_FAST
+    n, d, nq, k = 1_500_000, 128, 5, 10
+    idx = FlatIndex(d, metric=metric, dtype=dtype)
+    idx.set_mode(MODE_FAST)
+    idx.add_synthetic(n, seed=11)
+    X = oracle_mod.synth_rows(11, 0, n, d)
+    Q = oracle_mod.synth_rows(12, 0, nq, d)
+    D, I = idx.search(Q, k)
+    m = {"ip": oracle_mod.METRIC_IP, "l2": oracle_mod.METRIC_L2}[metric]
+    t = {"f32": oracle_mod.DTYPE_F32, "bf16": oracle_mod.DTYPE_BF16}[dtype]
+    Do, Io = oracle_mod.search(X, Q, k, metric=m, dtype=t)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+    assert idx.stats()["fast"] == nq
+
+
+def test_mfma_nan_row_and_add_after_search(oracle_mod):
+    """A NaN row never enters a candidate list; rows added after the first fast search of an F32
+    index must reach its bf16 shadow."""
+    from rag_amd.index import FlatIndex, MODE_FAST
+    rng = np.random.default_rng(13)
+    X = _unit(rng, 40000, 384)
+    X[123, 5] = np.nan
+    Q = _unit(rng, 6, 384)
+    _check(oracle_mod, X, Q, 10, "ip", "bf16", mode=MODE_FAST)
+    idx = FlatIndex(384, metric="l2", dtype="f32")
+    idx.set_mode(MODE_FAST)
+    idx.add(X[:35000])
+    idx.search(Q, 10)
+    X2 = np.concatenate([X[:35000], Q * 0.999 + 0.001 * X[35000:35006], X[35006:]]).astype(np.float32)
+    idx.add(X2[35000:])
+    D, I = idx.search(Q, 10)
+    Do, Io = oracle_mod.search(X2, Q, 10, metric=oracle_mod.METRIC_L2, dtype=oracle_mod.DTYPE_F32)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+    assert set(I[:, 0]) == set(range(35000, 35006))
+
+
 def test_mfma_certificate_falls_back_on_duplicates(oracle_mod):
     """More identical rows than the candidate lists hold: the certificate cannot hold for that
     query, so it must be re-run on the exact path and still be bit-exact."""
