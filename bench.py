@@ -179,6 +179,23 @@ def main() -> int:
         elapsed = float(t.item())
     stats = idx.stats()
     kind = idx.last_scan_time()["kind"]
+
+    # ---- the HBM-bound regime of the same scan (intensity = Q flop/B, so the scan is
+    # HBM-bound below Q ~ 300): the app's own Q = 1 and one full query tile, on the same resident shard
+    regimes = []
+    for Qs in (1, 256):
+        if Qs > Q:
+            continue
+        qs = q_dev[:Qs].contiguous()
+        idx.search_torch(qs, k)
+        ms = []
+        for _ in range(3):
+            idx.search_torch(qs, k)
+            ms.append(idx.last_scan_time()["ms"])
+        m = float(np.median(ms))
+        gbs = float(nloc) * d * (2 if args.dtype == "bf16" else 4) / (m * 1e-3) / 1e9
+        regimes.append({"queries": Qs, "scan_ms": round(m, 3), "achieved_GBs": round(gbs, 1),
+                        "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "qps_per_gpu": round(Qs / (m * 1e-3), 1)})
     embed = None
     if args.embed_chunks > 0:
         nloc_keep = nloc
@@ -254,6 +271,8 @@ def main() -> int:
         "cpu_baseline": cpu,
         "path": {"scan_kernel": kind, "queries_certified": stats["fast"], "queries_exact_rerun": stats["exact"]},
     }
+    out["hbm_bound_regime"] = {"note": "same kernel, same resident shard, small query batches; peak 8000 GB/s (spec), "
+                                       "~6300 GB/s measured streaming ceiling (MI355X_MICROARCH.md)", "cases": regimes}
     if check is not None:
         out["parity_check"] = check
     if embed is not None:

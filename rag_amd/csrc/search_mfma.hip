@@ -119,6 +119,11 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
             const uint4 v = *reinterpret_cast<const uint4*>(q_bf16 + qglob * d_pad + 16 * s + 8 * h);
             bq[s] = __builtin_bit_cast(bf16x8, v);
         }
+        // make hipcc wait for these loads HERE: with a register load still pending at the loop
+        // header its waitcnt pass puts a vmcnt(0) in front of the first MFMA of every unit, which
+        // drains the LDS-DMA prefetch that was just issued
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(bq[s]));
     }
 
     const int64_t row_begin = (int64_t)slice * slice_rows;
