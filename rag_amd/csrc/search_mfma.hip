@@ -29,9 +29,9 @@
 //     its partner's MFMAs; d = 768: 4 waves, one per SIMD, 512-register budget.  Waves whose 32
 //     queries are all padding only help with the loads.
 //   * corpus rows stream HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) in units of
-//     128 rows x 256 B through a ring of MF_NST buffers: MF_PD units are in flight while one is
-//     consumed, retired by counted s_waitcnt vmcnt(N) + a raw s_barrier (MF_PD = 1, 2 and 3
-//     measured within 2 % of each other in every regime; 1 keeps the indexing compile-time).
+//     128 rows x 256 B through a ring of PD + 1 buffers: PD units are in flight while one is
+//     consumed, retired by counted s_waitcnt vmcnt(N) + a raw s_barrier (PD = 3 where the scan is
+//     HBM-bound, 1 where it is MFMA-bound).
 //     Each 256-B row segment is XOR-swizzled by (row & 15) on the SOURCE side so the
 //     ds_read_b128 A-fragment reads are bank-conflict free.
 //   * workgroups that scan the same row slice carry the same (blockIdx % 8) so they share an
@@ -46,12 +46,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 #define MF_TILE_R 128
 #define MF_STAGE_BYTES (MF_TILE_R * 256)
-#define MF_PD 1                                    // LDS-DMA prefetch distance in units (1..3 measured equal)
-#define MF_NST (MF_PD + 1)                         // ring depth (units): MF_PD in flight + one being consumed
 #define MF_XXB 4                                   // ring depth of the per-tile xx / threshold buffers
-#define MF_XX_OFF (MF_NST * MF_STAGE_BYTES)
-#define MF_GT_OFF (MF_XX_OFF + MF_XXB * MF_TILE_R * 4)    // shared-threshold words: [MF_XXB][waves][64] u32
-#define MF_LDS_BYTES (MF_GT_OFF + MF_XXB * 8 * 256)
 #define MF_PH2_MAX 8192                            // candidate entries per (query, group) in LDS
 #define MF_SORT_MAX 1024                           // survivors re-scored and sorted per (query, group)
 #define MF_MIN_ROWS 32768
@@ -82,7 +77,11 @@ __device__ __forceinline__ void wait_units(int units)
 }
 
 // ---------------------------------------------------------------- phase 1
-template <int NKB, int KP, bool L2>
+// PD = LDS-DMA prefetch distance in units; the ring has PD + 1 buffers (PD in flight + one being
+// consumed).  Measured on one device at 100M x 384: PD = 3 is 5-15 % faster where the scan is
+// HBM-bound (one or two query tiles per slice), PD = 1 is 1-5 % faster where it is MFMA-bound
+// (the workgroups of a slice stay closer together in the XCD's L2); the plan picks.
+template <int NKB, int KP, bool L2, int PD>
 __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     const uint16_t* __restrict__ rows, const float* __restrict__ xx, int64_t n, int pitch_bytes,
     const uint16_t* __restrict__ q_bf16, int nq, int nq_pad, int nqt, int64_t slice_rows,
@@ -93,7 +92,12 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     constexpr int CAP = mf_cap(KP);
     constexpr int EPL = (CAP + 63) / 64;
     constexpr int KS = NKB * 8;                       // 16-wide k-steps per row
-    static_assert((MF_NST & (MF_NST - 1)) == 0 && MF_PD >= 1 && MF_PD <= 3, "ring of 2 or 4 buffers");
+    constexpr int MF_PD = PD;
+    constexpr int MF_NST = PD + 1;                     // ring depth (units)
+    constexpr int MF_XX_OFF = MF_NST * MF_STAGE_BYTES; // per-tile xx: [MF_XXB][128] f32
+    constexpr int MF_GT_OFF = MF_XX_OFF + MF_XXB * MF_TILE_R * 4;   // shared-threshold words: [MF_XXB][waves][64] u32
+    constexpr int MF_LDS_BYTES = MF_GT_OFF + MF_XXB * 8 * 256;
+    static_assert((MF_NST & (MF_NST - 1)) == 0 && PD >= 1 && PD <= 3, "ring of 2 or 4 buffers");
     __shared__ __attribute__((aligned(1024))) char lds[MF_LDS_BYTES];
 
     const int lane = threadIdx.x & 63;
@@ -621,6 +625,8 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
         if (v >= 8 && v <= spg_max * gmax && n / v >= MF_TILE_R) ns = v;
     }
     const int ngroups = (ns + spg_max - 1) / spg_max;
+    plan->pd = (nqt <= 2) ? 3 : 1;
+    if (const char* e = getenv("MI_MFMA_PD")) { const int v = atoi(e); if (v == 1 || v == 3) plan->pd = v; }
     plan->kprime = kp;
     plan->cap = cap;
     plan->nslices = ns;
@@ -634,14 +640,14 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
     return MI_OK;
 }
 
-template <int NKB, int KP, bool L2>
+template <int NKB, int KP, bool L2, int PD>
 static void launch_scan(hipStream_t st, const mi_mfma_plan* p, const uint16_t* rows, const float* xx, int64_t n,
                         int d_pad, const uint16_t* q_bf16, int nq, uint64_t* lists, int32_t* cnts, float* thrs, uint32_t* gthr)
 {
     const int qtile = 32 * mf_waves(NKB);
     const int nqt = p->nq_pad / qtile;
     const unsigned grid = (unsigned)(nqt * p->nslices);
-    mfma_scan_kernel<NKB, KP, L2><<<grid, 64 * mf_waves(NKB), 0, st>>>(rows, xx, n, d_pad * 2, q_bf16, nq, p->nq_pad, nqt,
+    mfma_scan_kernel<NKB, KP, L2, PD><<<grid, 64 * mf_waves(NKB), 0, st>>>(rows, xx, n, d_pad * 2, q_bf16, nq, p->nq_pad, nqt,
                                                                        p->slice_rows, lists, cnts, thrs, gthr);
 }
 
@@ -653,8 +659,10 @@ int mi_launch_mfma_scan(hipStream_t st, const mi_mfma_plan* p, int metric, const
     const bool l2 = metric == MI_METRIC_L2;
 #define MF_CASE(NKB_, KP_) \
     if (nkb == NKB_ && p->kprime == KP_) { \
-        if (l2) launch_scan<NKB_, KP_, true>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
-        else launch_scan<NKB_, KP_, false>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+        if (l2 && p->pd == 3) launch_scan<NKB_, KP_, true, 3>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+        else if (l2) launch_scan<NKB_, KP_, true, 1>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+        else if (p->pd == 3) launch_scan<NKB_, KP_, false, 3>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+        else launch_scan<NKB_, KP_, false, 1>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
         MI_HIP(hipGetLastError()); return MI_OK; }
     MF_CASE(1, 16) MF_CASE(1, 32) MF_CASE(1, 128)
     MF_CASE(3, 16) MF_CASE(3, 32) MF_CASE(3, 128)
