@@ -29,13 +29,34 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 __device__ __forceinline__ float bf2f(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
-// fp32 -> bf16 RNE for finite values (activations are finite by construction)
-__device__ __forceinline__ uint16_t f2bf(float f)
+// fp32 -> bf16, round-to-nearest-even: a plain cast is one v_cvt_pk_bf16_f32 per pair on gfx950
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack2(float lo, float hi)
 {
-    const uint32_t u = __builtin_bit_cast(uint32_t, f);
-    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
 }
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+// erf-GELU, x * 0.5 * (1 + erf(x / sqrt 2)), with erf from Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7, far below the bf16 rounding of the result): one v_rcp, one v_exp and a
+// degree-5 Horner chain instead of ocml's branchy erff.  (modeling_bert.py:334-337, activations.py GELUActivation)
+__device__ __forceinline__ float gelu_erf(float x)
+{
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = __builtin_fmaf(-poly, e, 1.0f);            // erf(|x| / sqrt 2)
+    const float erf_v = __builtin_copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf_v);
+}
 
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -77,31 +98,54 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
     }
 }
 
-// LayerNorm of a bf16 row (the GEMM epilogue already added bias and residual).
-template <int MAXE>
+// LayerNorm of a bf16 row (the GEMM epilogue already added bias and residual).  One wave per
+// token; lane l holds the 8 columns [8 l + 512 c, +8) of chunk c (16-byte loads and stores).
+template <int NCH>
 __global__ __launch_bounds__(256) void add_ln_kernel(const uint16_t* __restrict__ in, int64_t T, int H,
         const float* __restrict__ gamma, const float* __restrict__ beta, float eps, uint16_t* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= T) return;
-    float x[MAXE];
+    float x[NCH][8];
     float s = 0.0f;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-        const int c = lane + 64 * e;
-        x[e] = (c < H) ? bf2f(in[tok * H + c]) : 0.0f;
-        s += x[e];
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 8 * lane + 512 * c;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (col < H) v = *reinterpret_cast<const uint4*>(in + tok * H + col);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[c][2 * e] = __builtin_bit_cast(float, w[e] << 16);
+            x[c][2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xFFFF0000u);
+            s += x[c][2 * e] + x[c][2 * e + 1];
+        }
     }
     const float mean = wave_sum(s) / (float)H;
-    float v = 0.0f;
+    float v2 = 0.0f;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) { const int c = lane + 64 * e; const float dlt = (c < H) ? x[e] - mean : 0.0f; v += dlt * dlt; }
-    const float inv = 1.0f / sqrtf(wave_sum(v) / (float)H + eps);
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 8 * lane + 512 * c;
+        if (col < H) {
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-        const int c = lane + 64 * e;
-        if (c < H) out[tok * H + c] = f2bf((x[e] - mean) * inv * gamma[c] + beta[c]);
+            for (int e = 0; e < 8; ++e) { const float dlt = x[c][e] - mean; v2 += dlt * dlt; }
+        }
+    }
+    const float inv = 1.0f / sqrtf(wave_sum(v2) / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 8 * lane + 512 * c;
+        if (col < H) {
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma + col), g1 = *reinterpret_cast<const float4*>(gamma + col + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(beta + col), b1 = *reinterpret_cast<const float4*>(beta + col + 4);
+            uint4 o;
+            o.x = pack2((x[c][0] - mean) * inv * g0.x + b0.x, (x[c][1] - mean) * inv * g0.y + b0.y);
+            o.y = pack2((x[c][2] - mean) * inv * g0.z + b0.z, (x[c][3] - mean) * inv * g0.w + b0.w);
+            o.z = pack2((x[c][4] - mean) * inv * g1.x + b1.x, (x[c][5] - mean) * inv * g1.y + b1.y);
+            o.w = pack2((x[c][6] - mean) * inv * g1.z + b1.z, (x[c][7] - mean) * inv * g1.w + b1.w);
+            *reinterpret_cast<uint4*>(out + tok * H + col) = o;
+        }
     }
 }
 
@@ -112,10 +156,21 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const uint16_t* __restrict_
 // the 16-B chunk order inside a row is XOR-swizzled with ((row >> 1) & 7) on the SOURCE side,
 // which makes every ds_read_b128 fragment read conflict-free on 128-B rows.  Two stages of
 // 32 KB -> two workgroups per CU, i.e. two waves per SIMD hiding each other's waits.
+//
+// The product is formed transposed (W fragment as the MFMA A operand, activation fragment as
+// B): a lane then owns one output ROW (token) and its 16 accumulator registers walk the columns
+// in groups of four consecutive ones, so bias / GELU are per-register, the tile is parked in LDS
+// with 8- or 16-byte writes, and leaves as whole 256-B row segments (16-byte coalesced stores;
+// the residual is read the same way).  One rounding to bf16, after bias + residual.
+//
+// Workgroups that share an activation row tile (the N / 128 column tiles of one m-tile) carry
+// the same blockIdx % 8, i.e. run on one XCD and fetch that tile from HBM once.
 #define GM_BM 128
 #define GM_BN 128
 #define GM_BK 64
 #define GM_STAGE (2 * 128 * 128)   // A tile + W tile, bytes
+#define GM_TS16 272                // row stride of the parked bf16 tile (bytes)
+#define GM_TS32 528                // row stride of the parked fp32 tile (bytes)
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2 };
 
 __device__ __forceinline__ void lds_read2(bf16x8& a, bf16x8& b, unsigned addr)
@@ -126,15 +181,22 @@ __device__ __forceinline__ void lds_read2(bf16x8& a, bf16x8& b, unsigned addr)
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         const float* __restrict__ bias, const uint16_t* __restrict__ resid, uint16_t* __restrict__ C,
-        int M, int N, int K)
+        int M, int N, int K, int n_tiles, int m_tiles)
 {
-    __shared__ __attribute__((aligned(1024))) char lds[2 * GM_STAGE];
+    constexpr int LDS_BYTES = (EPI == EPI_RESID) ? GM_BM * GM_TS32 : 2 * GM_STAGE;
+    static_assert(LDS_BYTES >= 2 * GM_STAGE && GM_BM * GM_TS16 <= 2 * GM_STAGE, "LDS plan");
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, col = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * GM_BN;
-    const int m0 = blockIdx.y * GM_BM;
+    // XCD-aware tile order: blocks b, b + 8, ... (one XCD) walk the column tiles of m-tile
+    // 8 (j / n_tiles) + (b & 7); the host pads the grid to a multiple of 8 m-tiles.
+    const int bx = blockIdx.x;
+    const int mt = 8 * ((bx >> 3) / n_tiles) + (bx & 7);
+    if (mt >= m_tiles) return;                           // whole workgroup, before any barrier
+    const int n0 = ((bx >> 3) % n_tiles) * GM_BN;
+    const int m0 = mt * GM_BM;
 
     // LDS-DMA: 16 A pieces + 16 W pieces per stage; wave w issues A pieces 4w..4w+3 and W pieces 4w..4w+3.
     const int lr = lane >> 3, lt = lane & 7;
@@ -161,13 +223,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __res
         }
     };
 
+    // acc[ni][mi]: rows (registers) = columns n of C, lane column = row m of C
     f32x16 acc[2][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.0f;
+            for (int i = 0; i < 16; ++i) acc[ni][mi][i] = 0.0f;
 
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     const int sw = (col >> 1) & 7;
@@ -196,30 +259,58 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __res
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[c][0]), "+v"(af[c][1]), "+v"(wf[c][0]), "+v"(wf[c][1]));
             }
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][mi], wf[c][ni], acc[mi][ni], 0, 0, 0);
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][ni], af[c][mi], acc[ni][mi], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
 
-    // epilogue: lane owns column n (bias is lane-constant), registers walk the rows
+    // ---- epilogue 1: bias (+ GELU), park the tile in LDS as T[m][n] (everyone is past the last barrier)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-        const int n = n0 + wn * 64 + ni * 32 + col;
-        const float bv = bias[n];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int g = 0; g < 4; ++g) {
+            const int nl = wn * 64 + ni * 32 + 8 * g + 4 * h;            // local column of registers 4g..4g+3
+            const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + nl);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int m = m0 + wm * 64 + mi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (m < M) {
-                    float v = acc[mi][ni][i] + bv;
-                    if constexpr (EPI == EPI_GELU) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-                    if constexpr (EPI == EPI_RESID) v += bf2f(resid[(int64_t)m * N + n]);
-                    C[(int64_t)m * N + n] = f2bf(v);
+            for (int mi = 0; mi < 2; ++mi) {
+                const int ml = wm * 64 + mi * 32 + col;
+                float v0 = acc[ni][mi][4 * g + 0] + bv.x, v1 = acc[ni][mi][4 * g + 1] + bv.y;
+                float v2 = acc[ni][mi][4 * g + 2] + bv.z, v3 = acc[ni][mi][4 * g + 3] + bv.w;
+                if constexpr (EPI == EPI_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                if constexpr (EPI == EPI_RESID) {
+                    *reinterpret_cast<float4*>(lds + ml * GM_TS32 + nl * 4) = make_float4(v0, v1, v2, v3);
+                } else {
+                    *reinterpret_cast<uint2*>(lds + ml * GM_TS16 + nl * 2) = make_uint2(pack2(v0, v1), pack2(v2, v3));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- epilogue 2: whole 256-B row segments out (thread t: row t / 16 + 16 p, 16-B chunk t % 16)
+    {
+        const int r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int r = r0 + 16 * p;
+            const int m = m0 + r;
+            if (m < M) {
+                uint16_t* dst = C + (int64_t)m * N + n0 + 8 * ch;
+                if constexpr (EPI == EPI_RESID) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(lds + r * GM_TS32 + ch * 32);
+                    const float4 x1 = *reinterpret_cast<const float4*>(lds + r * GM_TS32 + ch * 32 + 16);
+                    const uint4 rv = *reinterpret_cast<const uint4*>(resid + (int64_t)m * N + n0 + 8 * ch);
+                    uint4 o;
+                    o.x = pack2(x0.x + __builtin_bit_cast(float, rv.x << 16), x0.y + __builtin_bit_cast(float, rv.x & 0xFFFF0000u));
+                    o.y = pack2(x0.z + __builtin_bit_cast(float, rv.y << 16), x0.w + __builtin_bit_cast(float, rv.y & 0xFFFF0000u));
+                    o.z = pack2(x1.x + __builtin_bit_cast(float, rv.z << 16), x1.y + __builtin_bit_cast(float, rv.z & 0xFFFF0000u));
+                    o.w = pack2(x1.z + __builtin_bit_cast(float, rv.w << 16), x1.w + __builtin_bit_cast(float, rv.w & 0xFFFF0000u));
+                    *reinterpret_cast<uint4*>(dst) = o;
+                } else {
+                    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(lds + r * GM_TS16 + ch * 16);
                 }
             }
         }
@@ -231,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __res
 // S^T = K Q^T (keys on accumulator rows, the query on the lane), so max/sum over keys are
 // in-register plus one cross-half exchange; P (bf16) feeds O^T = V^T P^T directly as the B
 // operand (the accumulator-as-operand k-permutation is matched by the V^T fragment reads).
-__global__ __launch_bounds__(256) void attn_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+__global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
         uint16_t* __restrict__ ctx, int L, int Lp, int H, float scale_log2e)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -288,7 +379,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const uint16_t* __restrict__ 
         for (int i = 0; i < 16; ++i) O[nb][i] = 0.0f;
 
     const int ksw = (col >> 2) & 3;
-    const float neg_big = -FLT_MAX;
     for (int kb = 0; kb < Lp / 32; ++kb) {
         // K fragments of this key block (A operand): row = key 32 kb + col
         bf16x8 kf[2];
@@ -316,23 +406,26 @@ __global__ __launch_bounds__(256) void attn_kernel(const uint16_t* __restrict__ 
             for (int i = 0; i < 16; ++i) S[i] = 0.0f;
             S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[nb][0], S, 0, 0, 0);
             S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[nb][1], S, 0, 0, 0);
-            // scores in log2 units: s * (dh^-1/2 * log2 e); a masked key is -FLT_MAX (finite, as in
-            // the reference's additive finfo.min mask, so an all-masked row softmaxes to uniform)
+            // scores in log2 units: s * (dh^-1/2 * log2 e) + mask, mask = 0 or -FLT_MAX (finite, as in
+            // the reference's additive finfo.min mask: the fma leaves a masked score at -FLT_MAX, so an
+            // all-masked row softmaxes to uniform)
             float tv[16];
-            float bm = neg_big;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float mkv = (i & 3) == 0 ? mk[i >> 2].x : (i & 3) == 1 ? mk[i >> 2].y : (i & 3) == 2 ? mk[i >> 2].z : mk[i >> 2].w;
-                tv[i] = (mkv == 0.0f) ? S[i] * scale_log2e : neg_big;
-                bm = fmaxf(bm, tv[i]);
+                tv[i] = __builtin_fmaf(S[i], scale_log2e, mkv);
             }
+            float bm = __builtin_fmaxf(__builtin_fmaxf(tv[0], tv[1]), tv[2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) bm = __builtin_fmaxf(__builtin_fmaxf(bm, tv[i]), tv[i + 1]);
+            bm = __builtin_fmaxf(bm, tv[15]);
             bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
             const float m_new = fmaxf(m_run[nb], bm);
-            const float alpha = exp2f(m_run[nb] - m_new);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_new);
             float ps = 0.0f;
             float p[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { p[i] = exp2f(tv[i] - m_new); ps += p[i]; }
+            for (int i = 0; i < 16; ++i) { p[i] = __builtin_amdgcn_exp2f(tv[i] - m_new); ps += p[i]; }
             l_run[nb] = l_run[nb] * alpha + ps;
             m_run[nb] = m_new;
 #pragma unroll
@@ -365,33 +458,64 @@ __global__ __launch_bounds__(256) void attn_kernel(const uint16_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------- masked mean pool + L2 normalise
+// One workgroup per sequence; wave w sums tokens i = w (mod 4), lane l the 8 columns
+// [8 l + 512 c, +8); the four partial sums meet in LDS.  fp32 throughout.
+template <int NCH>
 __global__ __launch_bounds__(256) void pool_kernel(const uint16_t* __restrict__ hid, const int32_t* __restrict__ mask,
         int L, int H, int normalize, float* __restrict__ out)
 {
+    __shared__ float part[4][NCH * 512];
     __shared__ float red[4];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t b = blockIdx.x;
-    float acc[4] = {0, 0, 0, 0};                 // H <= 1024
-    float cnt = 0.0f;
-    for (int i = 0; i < L; ++i) {
-        if (mask[b * L + i] == 0) continue;      // block-uniform
-        cnt += 1.0f;
+    float acc[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[c][e] = 0.0f;
+    int cnt = 0;
+    for (int i = wave; i < L; i += 4) {
+        if (mask[b * L + i] == 0) continue;      // wave-uniform
+        ++cnt;
         const uint16_t* row = hid + (b * L + i) * H;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const int c = t + 256 * e; if (c < H) acc[e] += bf2f(row[c]); }
+        for (int c = 0; c < NCH; ++c) {
+            const int col = 8 * lane + 512 * c;
+            if (col < H) {
+                const uint4 v = *reinterpret_cast<const uint4*>(row + col);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[c][2 * e] += __builtin_bit_cast(float, w[e] << 16);
+                    acc[c][2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xFFFF0000u);
+                }
+            }
+        }
     }
-    const float den = fmaxf(cnt, 1e-9f);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[wave][512 * c + 8 * lane + e] = acc[c][e];
+    if (lane == 0) red[wave] = (float)cnt;
+    __syncthreads();
+    const float den = fmaxf(red[0] + red[1] + red[2] + red[3], 1e-9f);
+    __syncthreads();
+    float v[2 * NCH];
     float ss = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { acc[e] = acc[e] / den; ss += acc[e] * acc[e]; }
+    for (int e = 0; e < 2 * NCH; ++e) {
+        const int col = t + 256 * e;
+        v[e] = (col < H) ? (part[0][col] + part[1][col] + part[2][col] + part[3][col]) / den : 0.0f;
+        ss += v[e] * v[e];
+    }
     ss = wave_sum(ss);
-    if ((t & 63) == 0) red[t >> 6] = ss;
+    if (lane == 0) red[wave] = ss;
     __syncthreads();
     const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int c = t + 256 * e;
-        if (c < H) out[b * H + c] = normalize ? acc[e] / nrm : acc[e];
+    for (int e = 0; e < 2 * NCH; ++e) {
+        const int col = t + 256 * e;
+        if (col < H) out[b * H + col] = normalize ? v[e] / nrm : v[e];
     }
 }
 
@@ -543,8 +667,9 @@ template <int EPI>
 static void launch_gemm(hipStream_t st, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* resid,
                         uint16_t* C, int M, int N, int K)
 {
-    dim3 grid(N / GM_BN, (M + GM_BM - 1) / GM_BM);
-    gemm_bf16_kernel<EPI><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K);
+    const int n_tiles = N / GM_BN, m_tiles = (M + GM_BM - 1) / GM_BM;
+    const unsigned grid = (unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles);
+    gemm_bf16_kernel<EPI><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K, n_tiles, m_tiles);
 }
 
 // All device pointers; B*L tokens.  Caller holds the encoder mutex and has set the device.
@@ -581,14 +706,15 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
         launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H);
         attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, scale_log2e);
         launch_gemm<EPI_RESID>(st, ctx, lw.Wo, lw.bo, h, tmp, (int)T, H, H);
-        if (H <= 384) add_ln_kernel<6><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
-        else add_ln_kernel<16><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
+        if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
+        else add_ln_kernel<2><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
         launch_gemm<EPI_GELU>(st, h, lw.Wi, lw.bi, nullptr, mid, (int)T, I, H);
         launch_gemm<EPI_RESID>(st, mid, lw.Wd, lw.bd, h, tmp, (int)T, H, I);
-        if (H <= 384) add_ln_kernel<6><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
-        else add_ln_kernel<16><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
+        if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
+        else add_ln_kernel<2><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
     }
-    pool_kernel<<<(unsigned)B, 256, 0, st>>>(h, mask, L, H, c.normalize, out);
+    if (H <= 512) pool_kernel<1><<<(unsigned)B, 256, 0, st>>>(h, mask, L, H, c.normalize, out);
+    else pool_kernel<2><<<(unsigned)B, 256, 0, st>>>(h, mask, L, H, c.normalize, out);
     MI_HIP(hipEventRecord(e->ev1, st));
     MI_HIP(hipGetLastError());
     e->timed = true;
