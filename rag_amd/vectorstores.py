@@ -328,6 +328,47 @@ class MI355VectorStore:
         tags = (kwargs.pop("tags", None) or []) + [type(self).__name__]
         return VectorStoreRetriever(self, tags=tags, **kwargs)
 
+    # ---- persistence.  LangChain's save_local pickles the docstore; this
+    # format executes nothing on load: rows.npy (fp32, or uint16 bf16 bit patterns) + store.json.
+    def save_local(self, folder_path: str, index_name: str = "index") -> None:
+        import json
+        import os
+        os.makedirs(folder_path, exist_ok=True)
+        n = self.index.ntotal
+        rows = self.index.reconstruct_n(0, n) if n else np.zeros((0, self.index.d), dtype=np.float32)
+        dtype = "bf16" if getattr(self.index, "dtype", 0) == 1 else "f32"
+        if dtype == "bf16":                      # stored values are exactly representable: keep the high halves
+            rows = (rows.view(np.uint32) >> 16).astype(np.uint16)
+        np.save(os.path.join(folder_path, f"{index_name}.rows.npy"), rows, allow_pickle=False)
+        meta = {"format": "mi355rag-store-1", "d": int(self.index.d), "dtype": dtype,
+                "distance_strategy": self.distance_strategy, "normalize_L2": bool(self._normalize_L2),
+                "ids": [self.index_to_docstore_id[i] for i in range(len(self.index_to_docstore_id))],
+                "documents": {k: {"page_content": v.page_content, "metadata": v.metadata}
+                              for k, v in self.docstore._dict.items()}}
+        with open(os.path.join(folder_path, f"{index_name}.store.json"), "w") as f:
+            json.dump(meta, f)
+
+    @classmethod
+    def load_local(cls, folder_path: str, embeddings: Any, index_name: str = "index", device: int = 0,
+                   index_factory: Optional[Callable[..., Any]] = None, **kwargs: Any) -> "MI355VectorStore":
+        import json
+        import os
+        with open(os.path.join(folder_path, f"{index_name}.store.json")) as f:
+            meta = json.load(f)
+        if meta.get("format") != "mi355rag-store-1":
+            raise ValueError(f"{folder_path}: not a mi355rag store")
+        rows = np.load(os.path.join(folder_path, f"{index_name}.rows.npy"), allow_pickle=False)
+        if meta["dtype"] == "bf16":
+            rows = (rows.astype(np.uint32) << 16).view(np.float32)
+        metric = "ip" if meta["distance_strategy"] == MAX_INNER_PRODUCT else "l2"
+        make = index_factory or (lambda d, metric, dtype: FlatIndex(d, metric=metric, dtype=dtype, device=device))
+        index = make(meta["d"], metric=metric, dtype=meta["dtype"])
+        if len(rows):
+            index.add(np.ascontiguousarray(rows, dtype=np.float32))
+        docs = {k: Document(page_content=v["page_content"], metadata=v["metadata"]) for k, v in meta["documents"].items()}
+        return cls(embeddings, index, InMemoryDocstore(docs), {i: _id for i, _id in enumerate(meta["ids"])},
+                   normalize_L2=meta["normalize_L2"], distance_strategy=meta["distance_strategy"], **kwargs)
+
     # ---- maintenance
     def delete_all(self) -> None:
         """reset_app_updated drops the store (advanced_rag.py:435-437)."""

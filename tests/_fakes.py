@@ -32,6 +32,12 @@ class OracleIndex:
         return oracle.search(self.X, np.asarray(q, dtype=np.float32), k, metric=self.metric,
                              dtype=self.dtype, id_base=self.id_base)
 
+    def reconstruct_n(self, row0, n):
+        x = self.X[row0:row0 + n]
+        if self.dtype == oracle.DTYPE_BF16:
+            x = oracle.bf16_to_f32(oracle.round_bf16(x))
+        return np.ascontiguousarray(x, dtype=np.float32)
+
     def reset(self):
         self.X = self.X[:0]
 
