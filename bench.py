@@ -34,6 +34,19 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic(rows_per_gpu, dim, dtype, queries):
+    """HBM-side bytes per scan launch from the committed rocprofv3 PMC pass (profiles/scan_traffic.json;
+    counters cannot be read from inside the timed process), or None when no pass covers this case."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "scan_traffic.json")) as f:
+            for c in json.load(f)["cases"]:
+                if (c["rows_per_gpu"], c["dim"], c["dtype"], c["queries"]) == (rows_per_gpu, dim, dtype, queries):
+                    return c["traffic_GB_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def bench_embed(args, dev, rank, world, barrier):
     """Second half of BASELINE.json's metric: chunks/s, bulk embedding of 256-token chunks with a
     MiniLM-L6 encoder (seeded random weights, synthetic token ids), data-parallel, no collective."""
@@ -195,7 +208,9 @@ def main() -> int:
         m = float(np.median(ms))
         gbs = float(nloc) * d * (2 if args.dtype == "bf16" else 4) / (m * 1e-3) / 1e9
         regimes.append({"queries": Qs, "scan_ms": round(m, 3), "achieved_GBs": round(gbs, 1),
-                        "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "qps_per_gpu": round(Qs / (m * 1e-3), 1)})
+                        "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "qps_per_gpu": round(Qs / (m * 1e-3), 1),
+                        "algorithmic_GB": round(float(nloc) * d * (2 if args.dtype == "bf16" else 4) / 1e9, 2),
+                        "traffic_GB": pmc_traffic(nloc, d, args.dtype, Qs)})
     embed = None
     if args.embed_chunks > 0:
         nloc_keep = nloc
@@ -218,7 +233,8 @@ def main() -> int:
     if kind == "mfma_bf16":
         ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(nloc, d, args.dtype, Q),
+                    "traffic_unit": "GB per launch (FETCH_SIZE PMC pass, profiles/r01_scan_pmc_v2.md)",
                     "kernel": "mfma_scan_kernel", "avg_launch_ms": round(avg_ms, 3),
                     "algorithmic_hbm_GBs": round(bytes_per_launch / (avg_ms * 1e-3) / 1e9, 1)}
     else:
