@@ -31,6 +31,8 @@ struct mi_ctx {
 int mi_ctx_device(mi_ctx* ctx) { return ctx->device; }
 hipStream_t mi_ctx_stream(mi_ctx* ctx) { return ctx->stream; }
 
+#define MI_ROW_SLACK 128
+
 // grow-only device buffer
 struct DevBuf {
     void* p = nullptr;
@@ -174,9 +176,11 @@ static int index_reserve_locked(mi_index* x, int64_t rows_total)
     void* nrows = nullptr;
     float* nxx = nullptr;
     const size_t row_bytes = (size_t)x->d_pad * x->elem();
-    hipError_t e = hipMalloc(&nrows, (size_t)rows_total * row_bytes);
+    // + MI_ROW_SLACK rows: the MFMA scan streams whole 128-row tiles and may read (never use) up
+    // to 127 rows past the last one
+    hipError_t e = hipMalloc(&nrows, (size_t)(rows_total + MI_ROW_SLACK) * row_bytes);
     if (e != hipSuccess) { mi_set_error("index: hipMalloc(%zu) for rows failed: %s", (size_t)rows_total * row_bytes, hipGetErrorString(e)); return MI_ERR_OOM; }
-    e = hipMalloc((void**)&nxx, (size_t)rows_total * sizeof(float));
+    e = hipMalloc((void**)&nxx, (size_t)(rows_total + MI_ROW_SLACK) * sizeof(float));
     if (e != hipSuccess) { (void)hipFree(nrows); mi_set_error("index: hipMalloc for norms failed: %s", hipGetErrorString(e)); return MI_ERR_OOM; }
     if (x->n > 0) {
         MI_HIP(hipMemcpyAsync(nrows, x->rows, (size_t)x->n * row_bytes, hipMemcpyDeviceToDevice, st));
@@ -419,7 +423,7 @@ static int ensure_shadow(mi_index* x, hipStream_t st)
 {
     if (x->shadow_cap < x->cap_rows) {
         MI_HIP(hipStreamSynchronize(st));
-        MI_TRY(x->shadow.ensure((size_t)x->cap_rows * x->d_pad_scan * sizeof(uint16_t)));
+        MI_TRY(x->shadow.ensure((size_t)(x->cap_rows + MI_ROW_SLACK) * x->d_pad_scan * sizeof(uint16_t)));
         x->shadow_cap = x->cap_rows;
         x->shadow_n = 0;
     }

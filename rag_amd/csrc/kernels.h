@@ -51,7 +51,7 @@ struct mi_mfma_plan {
     int nslices;       // row slices
     int ngroups;       // slice groups of the finish kernel (each <= spg slices)
     int spg;           // slices per group
-    int pd;            // LDS-DMA prefetch distance of the scan, 1 or 3 units
+    int pd;            // LDS-DMA prefetch distance of the scan: 3 (HBM-bound) or 2 (MFMA-bound)
     int64_t slice_rows;// rows per slice (multiple of the tile height)
     int nq_pad;        // queries padded to the query tile
     size_t list_bytes, cnt_bytes, thr_bytes;

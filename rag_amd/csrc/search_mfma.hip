@@ -77,10 +77,11 @@ __device__ __forceinline__ void wait_units(int units)
 }
 
 // ---------------------------------------------------------------- phase 1
-// PD = LDS-DMA prefetch distance in units; the ring has PD + 1 buffers (PD in flight + one being
-// consumed).  Measured on one device at 100M x 384: PD = 3 is 5-15 % faster where the scan is
-// HBM-bound (one or two query tiles per slice), PD = 1 is 1-5 % faster where it is MFMA-bound
-// (the workgroups of a slice stay closer together in the XCD's L2); the plan picks.
+// PD = LDS-DMA prefetch distance in units, ring of 4 buffers.  Measured on one device at
+// 100M x 384: a deep prefetch (PD = 3, issued at the top of an iteration) is 5-15 % faster where
+// the scan is HBM-bound (one or two query tiles per slice); a shallow one is 1-5 % faster where it
+// is MFMA-bound (the workgroups of a slice stay closer together in the XCD's L2): PD = 2, issued
+// at the bottom of the iteration.  The plan picks.
 template <int NKB, int KP, bool L2, int PD>
 __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     const uint16_t* __restrict__ rows, const float* __restrict__ xx, int64_t n, int pitch_bytes,
@@ -93,11 +94,11 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     constexpr int EPL = (CAP + 63) / 64;
     constexpr int KS = NKB * 8;                       // 16-wide k-steps per row
     constexpr int MF_PD = PD;
-    constexpr int MF_NST = PD + 1;                     // ring depth (units)
+    constexpr int MF_NST = 4;                          // ring depth (units)
     constexpr int MF_XX_OFF = MF_NST * MF_STAGE_BYTES; // per-tile xx: [MF_XXB][128] f32
     constexpr int MF_GT_OFF = MF_XX_OFF + MF_XXB * MF_TILE_R * 4;   // shared-threshold words: [MF_XXB][waves][64] u32
     constexpr int MF_LDS_BYTES = MF_GT_OFF + MF_XXB * 8 * 256;
-    static_assert((MF_NST & (MF_NST - 1)) == 0 && PD >= 1 && PD <= 3, "ring of 2 or 4 buffers");
+    static_assert(PD == 2 || PD == 3, "ring of 4 buffers: PD + 1 (+ 1 when the issue sits before the barrier)");
     __shared__ __attribute__((aligned(1024))) char lds[MF_LDS_BYTES];
 
     const int lane = threadIdx.x & 63;
@@ -141,43 +142,40 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     // belongs in that slot under the swizzle  slot = chunk ^ (row & 15).
     const int lr = lane >> 4;            // row within the piece
     const int lt = lane & 15;            // LDS slot
-    int src_sw[4];                       // byte offset of the chunk; (4p + lr) & 15 depends on p & 3
+    // Per-piece source pointers for tile 0, k-block 0 (PPW 64-bit registers); a unit adds one
+    // wave-uniform offset.  Tiles may run past row_end / n by up to MF_TILE_R - 1 rows: the index
+    // allocates that much slack behind its rows (capi.hip), and the filter masks those rows.
+    const char* pbase[PPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) src_sw[i] = (lt ^ ((4 * i + lr) & 15)) << 4;
-    const char* rows_b = reinterpret_cast<const char*>(rows);
-    const int64_t last_row = n - 1;
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave * PPW + i;
+        const int sw = (lt ^ ((4 * p + lr) & 15)) << 4;     // 16-B chunk that belongs in LDS slot lt of row 4p + lr
+        pbase[i] = reinterpret_cast<const char*>(rows) + (row_begin + 4 * p + lr) * (int64_t)pitch_bytes + sw;
+    }
 
-    // unit u = (tile, kb) lives in ring buffer u & 3; its tile's xx in xx buffer tile & 3
     // gthr[q]: the best threshold any workgroup has published for query q (orderable word, 0 =
     // none yet).  Any slice's K'-th best is a lower bound of the global K'-th best, so every
     // workgroup may filter with it; a stale value is only a weaker, still valid, threshold.  It
     // arrives by LDS-DMA (sc1: past this CU's L1) with the tile's first unit.
     const uint32_t* gsrc = gthr + (qglob - col) + (lane & 31);
+    // unit u = (tile, kb) lives in ring buffer u & (MF_NST - 1); its tile's xx in xx buffer tile & 3
     auto issue_unit = [&](int tile, int kb, int buf) {
-        const int64_t trow0 = row_begin + (int64_t)tile * MF_TILE_R;
         if (kb == 0)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc,
                 (lds_ptr_t)(lds + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256), 4, 0, 16);
         if constexpr (L2) {
             if (kb == 0 && wave == 0) {
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    int64_t r = trow0 + 64 * half + lane;
-                    if (r > last_row) r = last_row;
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xx + r),
+                for (int half = 0; half < 2; ++half)
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xx + row_begin + (int64_t)tile * MF_TILE_R + 64 * half + lane),
                         (lds_ptr_t)(lds + MF_XX_OFF + (tile & (MF_XXB - 1)) * (MF_TILE_R * 4) + half * 256), 4, 0, 0);
-                }
             }
         }
+        const int64_t off = (int64_t)tile * MF_TILE_R * pitch_bytes + kb * 256;      // wave-uniform
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int p = wave * PPW + i;                 // PPW is 4 or 8: p & 3 == i & 3
-            int64_t r = trow0 + 4 * p + lr;
-            if (r > last_row) r = last_row;               // never read past the matrix; masked later
-            const char* src = rows_b + r * pitch_bytes + kb * 256 + src_sw[i & 3];
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src,
-                (lds_ptr_t)(lds + buf * MF_STAGE_BYTES + p * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < PPW; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pbase[i] + off),
+                (lds_ptr_t)(lds + buf * MF_STAGE_BYTES + (wave * PPW + i) * 1024), 16, 0, 0);
     };
     auto issue_linear = [&](int u) {                      // u < nunits
         issue_unit(u / NKB, u % NKB, u & (MF_NST - 1));
@@ -229,9 +227,12 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb, ++u) {
             const int buf = u & (MF_NST - 1);
-            // unit u + MF_PD goes into the buffer everyone left at the last barrier (unit u - 1's);
-            // its (tile, kb) is known at compile time relative to this one
-            if (u + MF_PD < nunits) issue_unit(tile + (kb + MF_PD) / NKB, (kb + MF_PD) % NKB, (u + MF_PD) & (MF_NST - 1));
+            // PD = 3 (HBM-bound): unit u + 3 is issued here, into the buffer everyone left at the last
+            // barrier (unit u - 1's).  PD = 2 (MFMA-bound): unit u + 2 is issued at the BOTTOM of this
+            // iteration instead, behind the unit's MFMAs and before the wait, so the path from the
+            // barrier to the first MFMA is one LDS read; its buffer held unit u - 2.
+            const bool more = u + PD < nunits;
+            if constexpr (PD == 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
             if (active) {
                 // A fragments are read one k-step ahead of the MFMAs that consume them.  The reads
                 // are inline asm so hipcc cannot sink each one next to its use (it serialises
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][m], bq[kb * 8 + s], acc[m], 0, 0, 0);
                 }
             }
+            if constexpr (PD != 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
             // my LDS reads of this buffer are retired; my pieces of unit u + 1 have landed
             {
                 const int rem = nunits - 2 - u;           // units younger than u + 1 that exist
@@ -625,8 +627,8 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
         if (v >= 8 && v <= spg_max * gmax && n / v >= MF_TILE_R) ns = v;
     }
     const int ngroups = (ns + spg_max - 1) / spg_max;
-    plan->pd = (nqt <= 2) ? 3 : 1;
-    if (const char* e = getenv("MI_MFMA_PD")) { const int v = atoi(e); if (v == 1 || v == 3) plan->pd = v; }
+    plan->pd = (nqt <= 2) ? 3 : 2;
+    if (const char* e = getenv("MI_MFMA_PD")) { const int v = atoi(e); if (v == 2 || v == 3) plan->pd = v; }
     plan->kprime = kp;
     plan->cap = cap;
     plan->nslices = ns;
@@ -660,9 +662,9 @@ int mi_launch_mfma_scan(hipStream_t st, const mi_mfma_plan* p, int metric, const
 #define MF_CASE(NKB_, KP_) \
     if (nkb == NKB_ && p->kprime == KP_) { \
         if (l2 && p->pd == 3) launch_scan<NKB_, KP_, true, 3>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
-        else if (l2) launch_scan<NKB_, KP_, true, 1>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+        else if (l2) launch_scan<NKB_, KP_, true, 2>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
         else if (p->pd == 3) launch_scan<NKB_, KP_, false, 3>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
-        else launch_scan<NKB_, KP_, false, 1>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+        else launch_scan<NKB_, KP_, false, 2>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
         MI_HIP(hipGetLastError()); return MI_OK; }
     MF_CASE(1, 16) MF_CASE(1, 32) MF_CASE(1, 128)
     MF_CASE(3, 16) MF_CASE(3, 32) MF_CASE(3, 128)
