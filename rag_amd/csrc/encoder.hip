@@ -179,12 +179,15 @@ __device__ __forceinline__ void lds_read2(bf16x8& a, bf16x8& b, unsigned addr)
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+__global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         const float* __restrict__ bias, const uint16_t* __restrict__ resid, uint16_t* __restrict__ C,
         int M, int N, int K, int n_tiles, int m_tiles)
 {
-    constexpr int LDS_BYTES = (EPI == EPI_RESID) ? GM_BM * GM_TS32 : 2 * GM_STAGE;
-    static_assert(LDS_BYTES >= 2 * GM_STAGE && GM_BM * GM_TS16 <= 2 * GM_STAGE, "LDS plan");
+    // ONE 32-KB stage (A tile + W tile) and a two-barrier k-loop: the workgroup itself does not
+    // overlap its loads with its MFMAs; four workgroups per CU (36 KB LDS, <= 128 registers) do.
+    // Measured against the double-buffered two-per-CU form of this kernel: see DESIGN.md.
+    constexpr int PARK = (EPI == EPI_RESID) ? 64 * GM_TS32 : 64 * GM_TS16;     // half a tile (64 rows) parked at a time
+    constexpr int LDS_BYTES = PARK > GM_STAGE ? PARK : GM_STAGE;
     __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -203,23 +206,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __res
     const char* Ab = reinterpret_cast<const char*>(A);
     const char* Wb = reinterpret_cast<const char*>(W);
     const int64_t rowbytes = (int64_t)K * 2;
-    int64_t a_src[4], w_src[4];
+    const char *a_src[4], *w_src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int p = wave * 4 + i;
         const int r = 8 * p + lr;
         const int sw = (lt ^ ((r >> 1) & 7)) << 4;
         int ra = m0 + r; if (ra > M - 1) ra = M - 1;
-        a_src[i] = (int64_t)ra * rowbytes + sw;
-        w_src[i] = (int64_t)(n0 + r) * rowbytes + sw;     // N is a multiple of 128
+        a_src[i] = Ab + (int64_t)ra * rowbytes + sw;
+        w_src[i] = Wb + (int64_t)(n0 + r) * rowbytes + sw;     // N is a multiple of 128
     }
-    auto issue = [&](int kt, int buf) {
+    auto issue = [&](int kt) {
         const int koff = kt * (GM_BK * 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = wave * 4 + i;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ab + a_src[i] + koff), (lds_ptr_t)(lds + buf * GM_STAGE + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Wb + w_src[i] + koff), (lds_ptr_t)(lds + buf * GM_STAGE + 16384 + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + koff), (lds_ptr_t)(lds + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + koff), (lds_ptr_t)(lds + 16384 + p * 1024), 16, 0, 0);
         }
     };
 
@@ -234,26 +237,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __res
 
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     const int sw = (col >> 1) & 7;
-    const unsigned a_off = (unsigned)((wm * 64 + col) * 128);
-    const unsigned w_off = (unsigned)(16384 + (wn * 64 + col) * 128);
+    const unsigned a_off = lds_base + (unsigned)((wm * 64 + col) * 128);
+    const unsigned w_off = lds_base + (unsigned)(16384 + (wn * 64 + col) * 128);
 
     const int nkt = K / GM_BK;
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
-        const unsigned sb = lds_base + buf * GM_STAGE;
+        issue(kt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         bf16x8 af[2][2], wf[2][2];       // [parity][block]: rows +0 and +32 (offset 4096 B)
-        lds_read2(af[0][0], af[0][1], sb + a_off + (((0 + h) ^ sw) << 4));
-        lds_read2(wf[0][0], wf[0][1], sb + w_off + (((0 + h) ^ sw) << 4));
+        lds_read2(af[0][0], af[0][1], a_off + (((0 + h) ^ sw) << 4));
+        lds_read2(wf[0][0], wf[0][1], w_off + (((0 + h) ^ sw) << 4));
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int c = s & 1;
             if (s < 3) {
-                lds_read2(af[c ^ 1][0], af[c ^ 1][1], sb + a_off + (((2 * (s + 1) + h) ^ sw) << 4));
-                lds_read2(wf[c ^ 1][0], wf[c ^ 1][1], sb + w_off + (((2 * (s + 1) + h) ^ sw) << 4));
+                lds_read2(af[c ^ 1][0], af[c ^ 1][1], a_off + (((2 * (s + 1) + h) ^ sw) << 4));
+                lds_read2(wf[c ^ 1][0], wf[c ^ 1][1], w_off + (((2 * (s + 1) + h) ^ sw) << 4));
                 asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[c][0]), "+v"(af[c][1]), "+v"(wf[c][0]), "+v"(wf[c][1]));
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[c][0]), "+v"(af[c][1]), "+v"(wf[c][0]), "+v"(wf[c][1]));
@@ -264,39 +264,36 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __res
                 for (int mi = 0; mi < 2; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c][ni], af[c][mi], acc[ni][mi], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                    // every wave's reads are retired (lgkmcnt(0) above)
     }
 
-    // ---- epilogue 1: bias (+ GELU), park the tile in LDS as T[m][n] (everyone is past the last barrier)
+    // ---- epilogue, 64 rows (block mi of every wave) at a time: bias (+ GELU), park as T[r][n] with
+    // r = 32 wm + col, then whole 256-B row segments out (thread t: row t / 16 + 16 p, chunk t % 16)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int mi = 0; mi < 2; ++mi) {
+        const int rl = wm * 32 + col;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int nl = wn * 64 + ni * 32 + 8 * g + 4 * h;            // local column of registers 4g..4g+3
-            const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + nl);
+        for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int ml = wm * 64 + mi * 32 + col;
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wn * 64 + ni * 32 + 8 * g + 4 * h;            // local column of registers 4g..4g+3
+                const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + nl);
                 float v0 = acc[ni][mi][4 * g + 0] + bv.x, v1 = acc[ni][mi][4 * g + 1] + bv.y;
                 float v2 = acc[ni][mi][4 * g + 2] + bv.z, v3 = acc[ni][mi][4 * g + 3] + bv.w;
                 if constexpr (EPI == EPI_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
                 if constexpr (EPI == EPI_RESID) {
-                    *reinterpret_cast<float4*>(lds + ml * GM_TS32 + nl * 4) = make_float4(v0, v1, v2, v3);
+                    *reinterpret_cast<float4*>(lds + rl * GM_TS32 + nl * 4) = make_float4(v0, v1, v2, v3);
                 } else {
-                    *reinterpret_cast<uint2*>(lds + ml * GM_TS16 + nl * 2) = make_uint2(pack2(v0, v1), pack2(v2, v3));
+                    *reinterpret_cast<uint2*>(lds + rl * GM_TS16 + nl * 2) = make_uint2(pack2(v0, v1), pack2(v2, v3));
                 }
             }
         }
-    }
-    __syncthreads();
-    // ---- epilogue 2: whole 256-B row segments out (thread t: row t / 16 + 16 p, 16-B chunk t % 16)
-    {
+        __syncthreads();
         const int r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int r = r0 + 16 * p;
-            const int m = m0 + r;
+        for (int p = 0; p < 4; ++p) {
+            const int r = r0 + 16 * p;                                       // parked row: wm' = r / 32, col' = r % 32
+            const int m = m0 + (r >> 5) * 64 + mi * 32 + (r & 31);
             if (m < M) {
                 uint16_t* dst = C + (int64_t)m * N + n0 + 8 * ch;
                 if constexpr (EPI == EPI_RESID) {
@@ -314,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __res
                 }
             }
         }
+        if (mi == 0) __syncthreads();
     }
 }
 
