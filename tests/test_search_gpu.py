@@ -190,3 +190,66 @@ def test_merge_matches_oracle(oracle_mod):
         Do, Io = oracle_mod.topk_merge(ss, ids, k, om)
         np.testing.assert_array_equal(I.cpu().numpy(), Io)
         np.testing.assert_array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))
+
+
+def test_concurrent_searches_from_many_threads(oracle_mod):
+    """The reference enters the retriever from LangChain RunnableParallel workers and Gradio handler
+    threads (advanced_rag.py:302-305, 545-555): ctypes releases the GIL, the library serialises per
+    handle.  Eight threads hammer two indexes; every answer must equal the oracle's."""
+    import threading
+    from rag_amd.index import FlatIndex
+    rng = np.random.default_rng(21)
+    Xa, Xb = _unit(rng, 40000, 384), _unit(rng, 3000, 128)
+    ia = FlatIndex(384, metric="ip", dtype="bf16"); ia.add(Xa)
+    ib = FlatIndex(128, metric="l2", dtype="f32"); ib.add(Xb)
+    Qa, Qb = _unit(rng, 16, 384), _unit(rng, 16, 128)
+    Da, Ia = oracle_mod.search(Xa, Qa, 10, metric=oracle_mod.METRIC_IP, dtype=oracle_mod.DTYPE_BF16)
+    Db, Ib = oracle_mod.search(Xb, Qb, 5, metric=oracle_mod.METRIC_L2, dtype=oracle_mod.DTYPE_F32)
+    errors = []
+
+    def work(t):
+        try:
+            for it in range(20):
+                j = (t + it) % 16
+                if (t + it) % 2:
+                    D, I = ia.search(Qa[j:j + 1], 10)
+                    ok = np.array_equal(I[0], Ia[j]) and np.array_equal(D[0].view(np.uint32), Da[j].view(np.uint32))
+                else:
+                    D, I = ib.search(Qb[j:j + 1], 5)
+                    ok = np.array_equal(I[0], Ib[j]) and np.array_equal(D[0].view(np.uint32), Db[j].view(np.uint32))
+                if not ok:
+                    errors.append((t, it))
+        except Exception as e:          # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errors, errors[:3]
+
+
+def test_answer_is_invariant_under_row_permutation_and_batching(oracle_mod):
+    """Properties at a size the oracle does not need to see: (1) permuting the corpus permutes the
+    ids and leaves the scores bit-identical (no ties here); (2) a query's answer does not depend
+    on which batch it travelled in (Q = 1 vs a 300-query batch take different scan variants)."""
+    from rag_amd.index import FlatIndex
+    n, d, k = 200_000, 384, 10
+    idx = FlatIndex(d, metric="ip", dtype="bf16")
+    idx.add_synthetic(n, seed=31)
+    X = idx.reconstruct_n(0, n)
+    Q = oracle_mod.synth_rows(32, 0, 300, d)
+    D, I = idx.search(Q, k)
+    D1, I1 = idx.search(Q[7:8], k)
+    assert np.array_equal(I1[0], I[7]) and np.array_equal(D1[0].view(np.uint32), D[7].view(np.uint32))
+    perm = np.random.default_rng(33).permutation(n)
+    idx2 = FlatIndex(d, metric="ip", dtype="bf16")
+    idx2.add(X[perm])
+    D2, I2 = idx2.search(Q, k)
+    assert np.array_equal(D2.view(np.uint32), D.view(np.uint32))
+    assert np.array_equal(perm[I2], I)
+    # sortedness and self-consistency of the scores with the stored rows (canonical fp32 chain)
+    assert np.all(D[:, :-1] >= D[:, 1:])
+    for qi in (0, 150, 299):
+        for j in (0, k - 1):
+            want = np.float32(oracle_mod.score_pair(Q[qi], X[I[qi, j]], metric=oracle_mod.METRIC_IP, dtype=oracle_mod.DTYPE_BF16))
+            assert want.view(np.uint32) == D[qi, j].view(np.uint32)
