@@ -37,7 +37,16 @@
 //   * workgroups that scan the same row slice carry the same (blockIdx % 8) so they share an
 //     XCD's L2: a slice is fetched from HBM once per XCD pass, not once per query tile.
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 #include "kernels.h"
+
+template <int V> using IC = std::integral_constant<int, V>;
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(IC<I>{}), ...); }
+// f(IC<0>), f(IC<1>), ... f(IC<N-1>): a loop whose index is a compile-time constant in the body
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -142,16 +151,13 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     // belongs in that slot under the swizzle  slot = chunk ^ (row & 15).
     const int lr = lane >> 4;            // row within the piece
     const int lt = lane & 15;            // LDS slot
-    // Per-piece source pointers for tile 0, k-block 0 (PPW 64-bit registers); a unit adds one
-    // wave-uniform offset.  Tiles may run past row_end / n by up to MF_TILE_R - 1 rows: the index
-    // allocates that much slack behind its rows (capi.hip), and the filter masks those rows.
-    const char* pbase[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int p = wave * PPW + i;
-        const int sw = (lt ^ ((4 * p + lr) & 15)) << 4;     // 16-B chunk that belongs in LDS slot lt of row 4p + lr
-        pbase[i] = reinterpret_cast<const char*>(rows) + (row_begin + 4 * p + lr) * (int64_t)pitch_bytes + sw;
-    }
+    // Source of piece i = pb0 + (wave-uniform unit offset + i * 4 rows) + swizzled chunk.  The chunk
+    // that belongs in LDS slot lt of row 4p + lr is lt ^ ((4p + lr) & 15) = (lt ^ lr) ^ 4 (i & 3)
+    // (4p = 16 (..) + 4 (i & 3), lr < 4), so one register pair and one xor constant per piece do.
+    // Tiles may run past row_end / n by up to MF_TILE_R - 1 rows: the index allocates that much
+    // slack behind its rows (capi.hip), and the filter masks those rows.
+    const char* pb0 = reinterpret_cast<const char*>(rows) + (row_begin + 4 * wave * PPW + lr) * (int64_t)pitch_bytes;
+    const unsigned sw0 = (unsigned)(lt ^ lr) << 4;
 
     // gthr[q]: the best threshold any workgroup has published for query q (orderable word, 0 =
     // none yet).  Any slice's K'-th best is a lower bound of the global K'-th best, so every
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     // arrives by LDS-DMA (sc1: past this CU's L1) with the tile's first unit.
     const uint32_t* gsrc = gthr + (qglob - col) + (lane & 31);
     // unit u = (tile, kb) lives in ring buffer u & (MF_NST - 1); its tile's xx in xx buffer tile & 3
-    auto issue_unit = [&](int tile, int kb, int buf) {
+    auto issue_unit = [&](int tile, int kb, int buf) __attribute__((always_inline)) {
         if (kb == 0)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc,
                 (lds_ptr_t)(lds + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256), 4, 0, 16);
@@ -174,10 +180,10 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
         const int64_t off = (int64_t)tile * MF_TILE_R * pitch_bytes + kb * 256;      // wave-uniform
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pbase[i] + off),
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pb0 + (off + (int64_t)i * 4 * pitch_bytes) + (sw0 ^ ((i & 3) << 6))),
                 (lds_ptr_t)(lds + buf * MF_STAGE_BYTES + (wave * PPW + i) * 1024), 16, 0, 0);
     };
-    auto issue_linear = [&](int u) {                      // u < nunits
+    auto issue_linear = [&](int u) __attribute__((always_inline)) {                      // u < nunits
         issue_unit(u / NKB, u % NKB, u & (MF_NST - 1));
     };
 
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     uint64_t* const list = lists + ((int64_t)slice * nq_pad + qglob) * CAP;
 
     f32x16 acc[4];
-    auto init_acc = [&](int tile) {
+    auto init_acc = [&](int tile) __attribute__((always_inline)) {
         if constexpr (L2) {
             const float* xl = reinterpret_cast<const float*>(lds + MF_XX_OFF + (tile & (MF_XXB - 1)) * (MF_TILE_R * 4));
 #pragma unroll
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
 
     // A-fragment read address: row (32 m + col), chunk (2 s + h) ^ (row & 15)
     const int a_row_off = col * 256;
-    const int a_lo4 = lane & 15;
+    const unsigned a_swz = (unsigned)(h ^ (lane & 15)) << 4;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
     // ---- prologue: put MF_PD units in flight, retire unit 0
@@ -222,135 +228,151 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
         if (active) init_acc(0);
     }
 
-    int u = 0;
-    for (int tile = 0; tile < ntiles; ++tile) {
+    // ---- k-steps [S0, S0 + NS) of the unit in ring buffer `buf`, k-block KB of the queries.
+    // A fragments are read one k-step ahead of the MFMAs that consume them.  The reads are inline
+    // asm so hipcc cannot sink each one next to its use (it serialises ds_read -> wait -> MFMA
+    // otherwise); LDS returns in order, so with the 4 reads of step s+1 just issued, lgkmcnt(4)
+    // means the 4 reads of step s have landed.
+    auto chain = [&](int buf, auto KBc, auto S0c, auto NSc) __attribute__((always_inline)) {
+        constexpr int KB = decltype(KBc)::value, S0 = decltype(S0c)::value, NS = decltype(NSc)::value;
+        // row (32 m + col), chunk (2 s + h) ^ (row & 15): (2 s + h) ^ x = (h ^ x) ^ 2 s, and the row base
+        // is a multiple of 256, so step s is one xor with a constant on a single address register
+        const unsigned cur = (lds_base + buf * MF_STAGE_BYTES + a_row_off) | a_swz;
+        bf16x8 a[2][4];
+        lds_read4(a[0], cur ^ (S0 << 5));
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb, ++u) {
-            const int buf = u & (MF_NST - 1);
-            // PD = 3 (HBM-bound): unit u + 3 is issued here, into the buffer everyone left at the last
-            // barrier (unit u - 1's).  PD = 2 (MFMA-bound): unit u + 2 is issued at the BOTTOM of this
-            // iteration instead, behind the unit's MFMAs and before the wait, so the path from the
-            // barrier to the first MFMA is one LDS read; its buffer held unit u - 2.
-            const bool more = u + PD < nunits;
-            if constexpr (PD == 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
-            if (active) {
-                // A fragments are read one k-step ahead of the MFMAs that consume them.  The reads
-                // are inline asm so hipcc cannot sink each one next to its use (it serialises
-                // ds_read -> wait -> MFMA otherwise); LDS returns in order, so with the 4 reads of
-                // step s+1 just issued, lgkmcnt(4) means the 4 reads of step s have landed.
-                const unsigned cur = lds_base + buf * MF_STAGE_BYTES + a_row_off;
-                bf16x8 a[2][4];
-                lds_read4(a[0], cur + (((0 + h) ^ a_lo4) << 4));
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    if (s < 7) {
-                        lds_read4(a[(s + 1) & 1], cur + (((2 * (s + 1) + h) ^ a_lo4) << 4));
-                        asm volatile("s_waitcnt lgkmcnt(4)"
-                                     : "+v"(a[s & 1][0]), "+v"(a[s & 1][1]), "+v"(a[s & 1][2]), "+v"(a[s & 1][3]));
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)"
-                                     : "+v"(a[s & 1][0]), "+v"(a[s & 1][1]), "+v"(a[s & 1][2]), "+v"(a[s & 1][3]));
-                    }
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][m], bq[kb * 8 + s], acc[m], 0, 0, 0);
-                }
+        for (int t = 0; t < NS; ++t) {
+            const int s = S0 + t;
+            if (t < NS - 1) {
+                lds_read4(a[(t + 1) & 1], cur ^ ((s + 1) << 5));
+                asm volatile("s_waitcnt lgkmcnt(4)"
+                             : "+v"(a[t & 1][0]), "+v"(a[t & 1][1]), "+v"(a[t & 1][2]), "+v"(a[t & 1][3]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(a[t & 1][0]), "+v"(a[t & 1][1]), "+v"(a[t & 1][2]), "+v"(a[t & 1][3]));
             }
-            if constexpr (PD != 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
-            // my LDS reads of this buffer are retired; my pieces of unit u + 1 have landed
-            {
-                const int rem = nunits - 2 - u;           // units younger than u + 1 that exist
-                wait_units<PPW>(rem < 0 ? 0 : (rem < MF_PD - 1 ? rem : MF_PD - 1));
-            }
-            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t & 1][m], bq[KB * 8 + s], acc[m], 0, 0, 0);
         }
-        if (!active) continue;
+    };
 
-        // ---- filter: anything above the query's running threshold leaves the accumulators
-        const int64_t trow0 = row_begin + (int64_t)tile * MF_TILE_R;
-        {
-            const uint32_t gw = *reinterpret_cast<const uint32_t*>(lds + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256 + col * 4);
-            if (gw != 0) thr = __builtin_fmaxf(thr, mi_unord_f32(gw));
-        }
+    auto filter_tile = [&](int tile) __attribute__((always_inline)) {
+    // ---- filter: anything above the query's running threshold leaves the accumulators
+    // rows are < 2^32 (plan); rowbase changes per tile, so the 64 per-element row numbers are
+    // formed where they are used (hoisted out of the loop they would be spilled)
+    const uint32_t rowbase = (uint32_t)(row_begin + (int64_t)tile * MF_TILE_R) + 4u * (uint32_t)h;
+    const uint32_t rend = (uint32_t)row_end;
+    {
+        const uint32_t gw = *reinterpret_cast<const uint32_t*>(lds + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256 + col * 4);
+        if (gw != 0) thr = __builtin_fmaxf(thr, mi_unord_f32(gw));
+    }
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const f32x16 c = acc[m];
-            float bm = __builtin_fmaxf(c[0], c[1]);
+    for (int m = 0; m < 4; ++m) {
+        const f32x16 c = acc[m];
+        float bm = __builtin_fmaxf(c[0], c[1]);
 #pragma unroll
-            for (int i = 2; i < 16; ++i) bm = __builtin_fmaxf(bm, c[i]);
-            if (__builtin_amdgcn_ballot_w64(bm > thr) != 0) {
-                // ---------------- rare path: append the passing elements of this 32x32 block
+        for (int i = 2; i < 16; ++i) bm = __builtin_fmaxf(bm, c[i]);
+        if (__builtin_amdgcn_ballot_w64(bm > thr) != 0) {
+            // ---------------- rare path: append the passing elements of this 32x32 block
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float v = c[i];
-                    const int64_t row = trow0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    const bool pass = (v > thr) && (row < row_end);
-                    const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
-                    if (mask == 0) continue;
-                    const int partner = (int)((mask >> (lane ^ 32)) & 1ull);
-                    const int pos = cnt + ((h == 1) ? partner : 0);
-                    if (pass) list[pos] = ((uint64_t)mi_ord_f32(v) << 32) | (uint32_t)row;
-                    cnt += (pass ? 1 : 0) + partner;
+            for (int i = 0; i < 16; ++i) {
+                const float v = c[i];
+                const uint32_t row = rowbase + (uint32_t)(32 * m + (i & 3) + 8 * (i >> 2));
+                const bool pass = (v > thr) && (row < rend);
+                const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
+                if (mask == 0) continue;
+                const int partner = (int)((mask >> (lane ^ 32)) & 1ull);
+                const int pos = cnt + ((h == 1) ? partner : 0);
+                if (pass) list[pos] = ((uint64_t)mi_ord_f32(v) << 32) | row;
+                cnt += (pass ? 1 : 0) + partner;
+            }
+            // ---------------- compact the lists that can no longer take a whole block
+            uint64_t need = __builtin_amdgcn_ballot_w64(cnt > CAP - 32) & 0xFFFFFFFFull;
+            while (need) {
+                const int ql = __builtin_ctzll(need);
+                need &= need - 1;
+                const int cq = __builtin_amdgcn_readlane(cnt, ql);
+                uint64_t* lq = lists + ((int64_t)slice * nq_pad + (qglob - col + ql)) * CAP;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                uint64_t e[EPL];
+                uint32_t uo[EPL];
+#pragma unroll
+                for (int t = 0; t < EPL; ++t) {
+                    const int idx = t * 64 + lane;
+                    e[t] = (idx < cq) ? lq[idx] : 0ull;
+                    uo[t] = (uint32_t)(e[t] >> 32);     // 0 = below every valid score word
                 }
-                // ---------------- compact the lists that can no longer take a whole block
-                uint64_t need = __builtin_amdgcn_ballot_w64(cnt > CAP - 32) & 0xFFFFFFFFull;
-                while (need) {
-                    const int ql = __builtin_ctzll(need);
-                    need &= need - 1;
-                    const int cq = __builtin_amdgcn_readlane(cnt, ql);
-                    uint64_t* lq = lists + ((int64_t)slice * nq_pad + (qglob - col + ql)) * CAP;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    uint64_t e[EPL];
-                    uint32_t uo[EPL];
-#pragma unroll
-                    for (int t = 0; t < EPL; ++t) {
-                        const int idx = t * 64 + lane;
-                        e[t] = (idx < cq) ? lq[idx] : 0ull;
-                        uo[t] = (uint32_t)(e[t] >> 32);     // 0 = below every valid score word
-                    }
-                    // KP-th largest score word by bitwise binary search
-                    uint32_t T = 0;
-                    for (int bit = 31; bit >= 0; --bit) {
-                        const uint32_t cand = T | (1u << bit);
-                        int c2 = 0;
-#pragma unroll
-                        for (int t = 0; t < EPL; ++t)
-                            c2 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(uo[t] >= cand));
-                        if (c2 >= KP) T = cand;
-                    }
-                    int n_gt = 0;
+                // KP-th largest score word by bitwise binary search
+                uint32_t T = 0;
+                for (int bit = 31; bit >= 0; --bit) {
+                    const uint32_t cand = T | (1u << bit);
+                    int c2 = 0;
 #pragma unroll
                     for (int t = 0; t < EPL; ++t)
-                        n_gt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(uo[t] > T));
-                    const int need_eq = KP - n_gt;
-                    const uint64_t lt_mask = (1ull << lane) - 1ull;
-                    int base_gt = 0, base_eq = 0;
+                        c2 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(uo[t] >= cand));
+                    if (c2 >= KP) T = cand;
+                }
+                int n_gt = 0;
 #pragma unroll
-                    for (int t = 0; t < EPL; ++t) {
-                        const bool gt = uo[t] > T;
-                        const bool eq = (uo[t] == T);
-                        const uint64_t m_gt = __builtin_amdgcn_ballot_w64(gt);
-                        const uint64_t m_eq = __builtin_amdgcn_ballot_w64(eq);
-                        if (gt) lq[base_gt + __builtin_popcountll(m_gt & lt_mask)] = e[t];
-                        if (eq) {
-                            const int r = base_eq + __builtin_popcountll(m_eq & lt_mask);
-                            if (r < need_eq) lq[n_gt + r] = e[t];
-                        }
-                        base_gt += __builtin_popcountll(m_gt);
-                        base_eq += __builtin_popcountll(m_eq);
+                for (int t = 0; t < EPL; ++t)
+                    n_gt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(uo[t] > T));
+                const int need_eq = KP - n_gt;
+                const uint64_t lt_mask = (1ull << lane) - 1ull;
+                int base_gt = 0, base_eq = 0;
+#pragma unroll
+                for (int t = 0; t < EPL; ++t) {
+                    const bool gt = uo[t] > T;
+                    const bool eq = (uo[t] == T);
+                    const uint64_t m_gt = __builtin_amdgcn_ballot_w64(gt);
+                    const uint64_t m_eq = __builtin_amdgcn_ballot_w64(eq);
+                    if (gt) lq[base_gt + __builtin_popcountll(m_gt & lt_mask)] = e[t];
+                    if (eq) {
+                        const int r = base_eq + __builtin_popcountll(m_eq & lt_mask);
+                        if (r < need_eq) lq[n_gt + r] = e[t];
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    if (col == ql) {
-                        cnt = KP;
-                        const float tnew = mi_unord_f32(T);
-                        if (tnew > thr) {
-                            thr = tnew;
-                            if (h == 0) __hip_atomic_fetch_max(gthr + qglob, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
+                    base_gt += __builtin_popcountll(m_gt);
+                    base_eq += __builtin_popcountll(m_eq);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (col == ql) {
+                    cnt = KP;
+                    const float tnew = mi_unord_f32(T);
+                    if (tnew > thr) {
+                        thr = tnew;
+                        if (h == 0) __hip_atomic_fetch_max(gthr + qglob, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
         }
+    }
+    };
+
+    // my LDS reads are retired; my pieces of unit u + 1 have landed; everyone meets
+    auto end_of_unit = [&](int u) __attribute__((always_inline)) {
+        const int rem = nunits - 2 - u;               // units younger than u + 1 that exist
+        wait_units<PPW>(rem < 0 ? 0 : (rem < MF_PD - 1 ? rem : MF_PD - 1));
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // (A half-unit stagger of waves 4..7 against their SIMD partners was built and dropped in round
+    // 1: the second code path costs ~15 registers and hipcc spilled query fragments into the loop.)
+    int u = 0;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        static_for<NKB>([&](auto KBc) __attribute__((always_inline)) {
+            constexpr int kb = decltype(KBc)::value;
+            // PD = 3 (HBM-bound): unit u + 3 is issued here, into the buffer everyone left at the
+            // last barrier (unit u - 1's).  PD = 2 (MFMA-bound): unit u + 2 is issued at the BOTTOM
+            // of the iteration instead, behind the unit's MFMAs; its buffer held unit u - 2.
+            const bool more = u + PD < nunits;
+            if constexpr (PD == 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
+            if (active) chain(u & (MF_NST - 1), IC<kb>{}, IC<0>{}, IC<8>{});
+            if constexpr (PD != 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
+            end_of_unit(u);
+            ++u;
+        });
+        if (!active) continue;
+        filter_tile(tile);
         if (tile + 1 < ntiles) init_acc(tile + 1);
     }
 
