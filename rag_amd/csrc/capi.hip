@@ -64,6 +64,8 @@ struct mi_index {
     float* xx = nullptr;        // [cap_rows] canonical squared norms
     float* max_xx = nullptr;    // device scalar: max over rows of xx
     std::mutex mu;
+    // recorded behind every add on the stream that carried it; a search on another stream waits on it
+    hipEvent_t ev_data = nullptr;
     // search workspace (grow-only)
     DevBuf q_in, q_canon, q_bf16, qq, dense, pair_s, pair_i, lists, cnts, thrs, gthr, fail, part_s, part_i, sub_q, sub_qq, sub_s, sub_i, out_s, out_i;
     // stats
@@ -148,6 +150,8 @@ extern "C" int mi_index_create(mi_ctx* ctx, int dim, int metric, int dtype, mi_i
     e = hipMemsetAsync(x->max_xx, 0, 256, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(x->max_xx); delete x; mi_set_error("mi_index_create: memset failed"); return MI_ERR_HIP; }
+    e = hipEventCreateWithFlags(&x->ev_data, hipEventDisableTiming);
+    if (e != hipSuccess) { (void)hipFree(x->max_xx); delete x; mi_set_error("mi_index_create: hipEventCreate failed"); return MI_ERR_HIP; }
     *out = x;
     return MI_OK;
 }
@@ -165,6 +169,7 @@ extern "C" void mi_index_destroy(mi_index* idx)
                       &idx->sub_s, &idx->sub_i, &idx->out_s, &idx->out_i, &idx->shadow};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t ev : idx->ev_pool) (void)hipEventDestroy(ev);
+    if (idx->ev_data) (void)hipEventDestroy(idx->ev_data);
     delete idx;
 }
 
@@ -223,6 +228,7 @@ extern "C" int mi_index_add_dev(mi_index* idx, int64_t n, const void* x_dev, int
     MI_TRY(grow_for(idx, n));
     MI_TRY(mi_launch_ingest(st, x_dev, src_dtype, idx->d, n, idx->d, idx->d_pad, idx->dtype, row_ptr(idx, idx->n)));
     MI_TRY(mi_launch_row_norms(st, row_ptr(idx, idx->n), idx->dtype, n, idx->d_pad, idx->xx + idx->n, idx->max_xx));
+    MI_HIP(hipEventRecord(idx->ev_data, st));
     idx->n += n;
     return MI_OK;
 }
@@ -445,6 +451,7 @@ static int search_dev_locked(mi_index* x, int64_t nq64, const float* q_dev, int 
     if (nq == 0) return MI_OK;
     const int64_t n = x->n;
     x->ev_used = 0;
+    if (n > 0) MI_HIP(hipStreamWaitEvent(st, x->ev_data, 0));      // rows added on another stream
 
     bool fast = false;
     mi_mfma_plan plan{};

@@ -51,6 +51,7 @@ struct mi_mfma_plan {
     int nslices;       // row slices
     int ngroups;       // slice groups of the finish kernel (each <= spg slices)
     int spg;           // slices per group
+    int m16;           // 1: score with 16x16x32 MFMAs (MFMA-bound variant only)
     int pd;            // LDS-DMA prefetch distance of the scan: 3 (HBM-bound) or 2 (MFMA-bound)
     int64_t slice_rows;// rows per slice (multiple of the tile height)
     int nq_pad;        // queries padded to the query tile

@@ -50,6 +50,7 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -91,7 +92,9 @@ __device__ __forceinline__ void wait_units(int units)
 // the scan is HBM-bound (one or two query tiles per slice); a shallow one is 1-5 % faster where it
 // is MFMA-bound (the workgroups of a slice stay closer together in the XCD's L2): PD = 2, issued
 // at the bottom of the iteration.  The plan picks.
-template <int NKB, int KP, bool L2, int PD>
+// M16: score with v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same LDS image, same bytes read,
+// same MFMA cycles per k; the guide measured a higher sustained clock on that shape).
+template <int NKB, int KP, bool L2, int PD, bool M16>
 __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     const uint16_t* __restrict__ rows, const float* __restrict__ xx, int64_t n, int pitch_bytes,
     const uint16_t* __restrict__ q_bf16, int nq, int nq_pad, int nqt, int64_t slice_rows,
@@ -125,19 +128,36 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     const int64_t qglob = (int64_t)qt * (32 * WAVES) + wave * 32 + col;   // this lane's query
     const bool active = (int64_t)qt * (32 * WAVES) + wave * 32 < nq;      // wave-uniform
 
-    // ---- B fragments: lane (col, h) holds query qglob, dims [16 s + 8 h, +8)
-    bf16x8 bq[KS];
+    const int64_t qbase = (int64_t)qt * (32 * WAVES) + wave * 32;         // first query of this wave
+    const int l15 = lane & 15, g4 = lane >> 4;                            // 16x16x32 lane coordinates
+
+    // ---- B fragments.  32x32x16: lane (col, h) holds query qglob, dims [16 s + 8 h, +8).
+    // 16x16x32: lane (l15, g4) holds queries qbase + 16 cb + l15 (cb = 0, 1), dims [32 s + 8 g4, +8).
+    bf16x8 bq[M16 ? 1 : KS];
+    bf16x8 bq16[M16 ? KS / 2 : 1][2];
     if (active) {
+        if constexpr (M16) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const uint4 v = *reinterpret_cast<const uint4*>(q_bf16 + qglob * d_pad + 16 * s + 8 * h);
-            bq[s] = __builtin_bit_cast(bf16x8, v);
+            for (int s = 0; s < KS / 2; ++s)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(q_bf16 + (qbase + 16 * cb + l15) * d_pad + 32 * s + 8 * g4);
+                    bq16[s][cb] = __builtin_bit_cast(bf16x8, v);
+                }
+#pragma unroll
+            for (int s = 0; s < KS / 2; ++s) asm volatile("" :: "v"(bq16[s][0]), "v"(bq16[s][1]));
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const uint4 v = *reinterpret_cast<const uint4*>(q_bf16 + qglob * d_pad + 16 * s + 8 * h);
+                bq[s] = __builtin_bit_cast(bf16x8, v);
+            }
+            // make hipcc wait for these loads HERE: with a register load still pending at the loop
+            // header its waitcnt pass puts a vmcnt(0) in front of the first MFMA of every unit, which
+            // drains the LDS-DMA prefetch that was just issued
+#pragma unroll
+            for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(bq[s]));
         }
-        // make hipcc wait for these loads HERE: with a register load still pending at the loop
-        // header its waitcnt pass puts a vmcnt(0) in front of the first MFMA of every unit, which
-        // drains the LDS-DMA prefetch that was just issued
-#pragma unroll
-        for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(bq[s]));
     }
 
     const int64_t row_begin = (int64_t)slice * slice_rows;
@@ -191,10 +211,33 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     float thr = -__builtin_inff();
     int cnt = 0;
     uint64_t* const list = lists + ((int64_t)slice * nq_pad + qglob) * CAP;
+    float thr2[2] = {-__builtin_inff(), -__builtin_inff()};       // 16x16x32: the lane's two queries
+    int cnt2[2] = {0, 0};
 
-    f32x16 acc[4];
+    f32x16 acc[M16 ? 1 : 4];
+    f32x4 acc16[M16 ? 8 : 1][2];                                  // [16-row block][16-query block]
     auto init_acc = [&](int tile) __attribute__((always_inline)) {
-        if constexpr (L2) {
+        if constexpr (M16) {
+            if constexpr (L2) {
+                const float* xl = reinterpret_cast<const float*>(lds + MF_XX_OFF + (tile & (MF_XXB - 1)) * (MF_TILE_R * 4));
+#pragma unroll
+                for (int rb = 0; rb < 8; ++rb) {
+                    const float4 v = *reinterpret_cast<const float4*>(xl + 16 * rb + 4 * g4);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        acc16[rb][cb][0] = -0.5f * v.x; acc16[rb][cb][1] = -0.5f * v.y;
+                        acc16[rb][cb][2] = -0.5f * v.z; acc16[rb][cb][3] = -0.5f * v.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc16[rb][cb][i] = 0.0f;
+            }
+        } else if constexpr (L2) {
             const float* xl = reinterpret_cast<const float*>(lds + MF_XX_OFF + (tile & (MF_XXB - 1)) * (MF_TILE_R * 4));
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -257,95 +300,185 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
         }
     };
 
-    auto filter_tile = [&](int tile) __attribute__((always_inline)) {
-    // ---- filter: anything above the query's running threshold leaves the accumulators
-    // rows are < 2^32 (plan); rowbase changes per tile, so the 64 per-element row numbers are
-    // formed where they are used (hoisted out of the loop they would be spilled)
-    const uint32_t rowbase = (uint32_t)(row_begin + (int64_t)tile * MF_TILE_R) + 4u * (uint32_t)h;
-    const uint32_t rend = (uint32_t)row_end;
-    {
-        const uint32_t gw = *reinterpret_cast<const uint32_t*>(lds + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256 + col * 4);
-        if (gw != 0) thr = __builtin_fmaxf(thr, mi_unord_f32(gw));
-    }
+    // 16x16x32: per 32-wide k-step s (4 per unit) eight A fragments, rows 16 rb + l15, chunk
+    // (4 s + g4) ^ l15 = (g4 ^ l15) ^ 4 s; read and consumed four row blocks at a time, one
+    // group ahead, 8 MFMAs (4 row blocks x 2 query blocks, 16 cycles each) per group.
+    auto chain16 = [&](int buf, auto KBc) __attribute__((always_inline)) {
+        constexpr int KB = decltype(KBc)::value;
+        const unsigned cur = (lds_base + buf * MF_STAGE_BYTES + l15 * 256) | ((unsigned)(g4 ^ l15) << 4);
+        bf16x8 a[2][4];
+        auto rd = [&](bf16x8 (&f)[4], int grp) __attribute__((always_inline)) {     // grp = 2 s + half
+            const unsigned ad = cur ^ ((unsigned)(grp >> 1) << 6);
+            if (grp & 1)
+                asm volatile("ds_read_b128 %0, %4 offset:16384\n\tds_read_b128 %1, %4 offset:20480\n\t"
+                             "ds_read_b128 %2, %4 offset:24576\n\tds_read_b128 %3, %4 offset:28672"
+                             : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]) : "v"(ad));
+            else
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\t"
+                             "ds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %4 offset:12288"
+                             : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]) : "v"(ad));
+        };
+        rd(a[0], 0);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const f32x16 c = acc[m];
-        float bm = __builtin_fmaxf(c[0], c[1]);
-#pragma unroll
-        for (int i = 2; i < 16; ++i) bm = __builtin_fmaxf(bm, c[i]);
-        if (__builtin_amdgcn_ballot_w64(bm > thr) != 0) {
-            // ---------------- rare path: append the passing elements of this 32x32 block
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float v = c[i];
-                const uint32_t row = rowbase + (uint32_t)(32 * m + (i & 3) + 8 * (i >> 2));
-                const bool pass = (v > thr) && (row < rend);
-                const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
-                if (mask == 0) continue;
-                const int partner = (int)((mask >> (lane ^ 32)) & 1ull);
-                const int pos = cnt + ((h == 1) ? partner : 0);
-                if (pass) list[pos] = ((uint64_t)mi_ord_f32(v) << 32) | row;
-                cnt += (pass ? 1 : 0) + partner;
+        for (int t = 0; t < 8; ++t) {
+            if (t < 7) {
+                rd(a[(t + 1) & 1], t + 1);
+                asm volatile("s_waitcnt lgkmcnt(4)"
+                             : "+v"(a[t & 1][0]), "+v"(a[t & 1][1]), "+v"(a[t & 1][2]), "+v"(a[t & 1][3]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(a[t & 1][0]), "+v"(a[t & 1][1]), "+v"(a[t & 1][2]), "+v"(a[t & 1][3]));
             }
-            // ---------------- compact the lists that can no longer take a whole block
-            uint64_t need = __builtin_amdgcn_ballot_w64(cnt > CAP - 32) & 0xFFFFFFFFull;
-            while (need) {
-                const int ql = __builtin_ctzll(need);
-                need &= need - 1;
-                const int cq = __builtin_amdgcn_readlane(cnt, ql);
-                uint64_t* lq = lists + ((int64_t)slice * nq_pad + (qglob - col + ql)) * CAP;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                uint64_t e[EPL];
-                uint32_t uo[EPL];
 #pragma unroll
-                for (int t = 0; t < EPL; ++t) {
-                    const int idx = t * 64 + lane;
-                    e[t] = (idx < cq) ? lq[idx] : 0ull;
-                    uo[t] = (uint32_t)(e[t] >> 32);     // 0 = below every valid score word
-                }
-                // KP-th largest score word by bitwise binary search
-                uint32_t T = 0;
-                for (int bit = 31; bit >= 0; --bit) {
-                    const uint32_t cand = T | (1u << bit);
-                    int c2 = 0;
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int t = 0; t < EPL; ++t)
-                        c2 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(uo[t] >= cand));
-                    if (c2 >= KP) T = cand;
-                }
-                int n_gt = 0;
+                for (int cb = 0; cb < 2; ++cb)
+                    acc16[4 * (t & 1) + r][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        a[t & 1][r], bq16[KB * 4 + (t >> 1)][cb], acc16[4 * (t & 1) + r][cb], 0, 0, 0);
+        }
+    };
+
+    // Compacts the list of the wave's query ql (0..31) from cq entries to its KP best; returns the
+    // KP-th largest score word.  The whole wave takes part.
+    auto compact_list = [&](int ql, int cq) __attribute__((always_inline)) -> uint32_t {
+        uint64_t* lq = lists + ((int64_t)slice * nq_pad + (qbase + ql)) * CAP;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        uint64_t e[EPL];
+        uint32_t uo[EPL];
 #pragma unroll
-                for (int t = 0; t < EPL; ++t)
-                    n_gt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(uo[t] > T));
-                const int need_eq = KP - n_gt;
-                const uint64_t lt_mask = (1ull << lane) - 1ull;
-                int base_gt = 0, base_eq = 0;
+        for (int t = 0; t < EPL; ++t) {
+            const int idx = t * 64 + lane;
+            e[t] = (idx < cq) ? lq[idx] : 0ull;
+            uo[t] = (uint32_t)(e[t] >> 32);     // 0 = below every valid score word
+        }
+        // KP-th largest score word by bitwise binary search
+        uint32_t T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = T | (1u << bit);
+            int c2 = 0;
 #pragma unroll
-                for (int t = 0; t < EPL; ++t) {
-                    const bool gt = uo[t] > T;
-                    const bool eq = (uo[t] == T);
-                    const uint64_t m_gt = __builtin_amdgcn_ballot_w64(gt);
-                    const uint64_t m_eq = __builtin_amdgcn_ballot_w64(eq);
-                    if (gt) lq[base_gt + __builtin_popcountll(m_gt & lt_mask)] = e[t];
-                    if (eq) {
-                        const int r = base_eq + __builtin_popcountll(m_eq & lt_mask);
-                        if (r < need_eq) lq[n_gt + r] = e[t];
+            for (int t = 0; t < EPL; ++t)
+                c2 += __builtin_popcountll(__builtin_amdgcn_ballot_w64(uo[t] >= cand));
+            if (c2 >= KP) T = cand;
+        }
+        int n_gt = 0;
+#pragma unroll
+        for (int t = 0; t < EPL; ++t)
+            n_gt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(uo[t] > T));
+        const int need_eq = KP - n_gt;
+        const uint64_t lt_mask = (1ull << lane) - 1ull;
+        int base_gt = 0, base_eq = 0;
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const bool gt = uo[t] > T;
+            const bool eq = (uo[t] == T);
+            const uint64_t m_gt = __builtin_amdgcn_ballot_w64(gt);
+            const uint64_t m_eq = __builtin_amdgcn_ballot_w64(eq);
+            if (gt) lq[base_gt + __builtin_popcountll(m_gt & lt_mask)] = e[t];
+            if (eq) {
+                const int r = base_eq + __builtin_popcountll(m_eq & lt_mask);
+                if (r < need_eq) lq[n_gt + r] = e[t];
+            }
+            base_gt += __builtin_popcountll(m_gt);
+            base_eq += __builtin_popcountll(m_eq);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        return T;
+    };
+
+    // ---- filter: anything above the query's running threshold leaves the accumulators.
+    // Rows are < 2^32 (plan); the row base changes per tile, so the per-element row numbers are
+    // formed where they are used (hoisted out of the loop they would be spilled).
+    auto filter_tile = [&](int tile) __attribute__((always_inline)) {
+        const uint32_t rend = (uint32_t)row_end;
+        const char* gslot = lds + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256;
+        if constexpr (M16) {
+            // the lane holds rows 16 rb + 4 g4 + reg of queries 16 cb + l15; a query's results sit in
+            // the four lanes l15 + 16 g
+            const uint32_t rowbase = (uint32_t)(row_begin + (int64_t)tile * MF_TILE_R) + 4u * (uint32_t)g4;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const uint32_t gw = *reinterpret_cast<const uint32_t*>(gslot + (16 * cb + l15) * 4);
+                if (gw != 0) thr2[cb] = __builtin_fmaxf(thr2[cb], mi_unord_f32(gw));
+                uint64_t* const list16 = lists + ((int64_t)slice * nq_pad + qbase + 16 * cb + l15) * CAP;
+#pragma unroll
+                for (int rp = 0; rp < 4; ++rp) {                  // 32 rows at a time, as the list capacity assumes
+                    float bm = __builtin_fmaxf(acc16[2 * rp][cb][0], acc16[2 * rp][cb][1]);
+#pragma unroll
+                    for (int i = 2; i < 8; ++i) bm = __builtin_fmaxf(bm, acc16[2 * rp + (i >> 2)][cb][i & 3]);
+                    if (__builtin_amdgcn_ballot_w64(bm > thr2[cb]) == 0) continue;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float v = acc16[2 * rp + (i >> 2)][cb][i & 3];
+                        const uint32_t row = rowbase + (uint32_t)(16 * (2 * rp + (i >> 2)) + (i & 3));
+                        const bool pass = (v > thr2[cb]) && (row < rend);
+                        const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
+                        if (mask == 0) continue;
+                        const int b0 = (int)((mask >> l15) & 1ull), b1 = (int)((mask >> (l15 + 16)) & 1ull);
+                        const int b2 = (int)((mask >> (l15 + 32)) & 1ull), b3 = (int)((mask >> (l15 + 48)) & 1ull);
+                        const int lower = (g4 > 0 ? b0 : 0) + (g4 > 1 ? b1 : 0) + (g4 > 2 ? b2 : 0);
+                        if (pass) list16[cnt2[cb] + lower] = ((uint64_t)mi_ord_f32(v) << 32) | row;
+                        cnt2[cb] += b0 + b1 + b2 + b3;
                     }
-                    base_gt += __builtin_popcountll(m_gt);
-                    base_eq += __builtin_popcountll(m_eq);
+                    uint64_t need = __builtin_amdgcn_ballot_w64(cnt2[cb] > CAP - 32) & 0xFFFFull;
+                    while (need) {
+                        const int ql = __builtin_ctzll(need);
+                        need &= need - 1;
+                        const uint32_t T = compact_list(16 * cb + ql, __builtin_amdgcn_readlane(cnt2[cb], ql));
+                        if (l15 == ql) {
+                            cnt2[cb] = KP;
+                            const float tnew = mi_unord_f32(T);
+                            if (tnew > thr2[cb]) {
+                                thr2[cb] = tnew;
+                                if (g4 == 0) __hip_atomic_fetch_max(gthr + qbase + 16 * cb + l15, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                if (col == ql) {
-                    cnt = KP;
-                    const float tnew = mi_unord_f32(T);
-                    if (tnew > thr) {
-                        thr = tnew;
-                        if (h == 0) __hip_atomic_fetch_max(gthr + qglob, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            const uint32_t rowbase = (uint32_t)(row_begin + (int64_t)tile * MF_TILE_R) + 4u * (uint32_t)h;
+            {
+                const uint32_t gw = *reinterpret_cast<const uint32_t*>(gslot + col * 4);
+                if (gw != 0) thr = __builtin_fmaxf(thr, mi_unord_f32(gw));
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x16 c = acc[m];
+                float bm = __builtin_fmaxf(c[0], c[1]);
+#pragma unroll
+                for (int i = 2; i < 16; ++i) bm = __builtin_fmaxf(bm, c[i]);
+                if (__builtin_amdgcn_ballot_w64(bm > thr) == 0) continue;
+                // ---------------- rare path: append the passing elements of this 32x32 block
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float v = c[i];
+                    const uint32_t row = rowbase + (uint32_t)(32 * m + (i & 3) + 8 * (i >> 2));
+                    const bool pass = (v > thr) && (row < rend);
+                    const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
+                    if (mask == 0) continue;
+                    const int partner = (int)((mask >> (lane ^ 32)) & 1ull);
+                    const int pos = cnt + ((h == 1) ? partner : 0);
+                    if (pass) list[pos] = ((uint64_t)mi_ord_f32(v) << 32) | row;
+                    cnt += (pass ? 1 : 0) + partner;
+                }
+                // ---------------- compact the lists that can no longer take a whole block
+                uint64_t need = __builtin_amdgcn_ballot_w64(cnt > CAP - 32) & 0xFFFFFFFFull;
+                while (need) {
+                    const int ql = __builtin_ctzll(need);
+                    need &= need - 1;
+                    const uint32_t T = compact_list(ql, __builtin_amdgcn_readlane(cnt, ql));
+                    if (col == ql) {
+                        cnt = KP;
+                        const float tnew = mi_unord_f32(T);
+                        if (tnew > thr) {
+                            thr = tnew;
+                            if (h == 0) __hip_atomic_fetch_max(gthr + qglob, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
                 }
             }
         }
-    }
     };
 
     // my LDS reads are retired; my pieces of unit u + 1 have landed; everyone meets
@@ -366,7 +499,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
             // of the iteration instead, behind the unit's MFMAs; its buffer held unit u - 2.
             const bool more = u + PD < nunits;
             if constexpr (PD == 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
-            if (active) chain(u & (MF_NST - 1), IC<kb>{}, IC<0>{}, IC<8>{});
+            if (active) { if constexpr (M16) chain16(u & (MF_NST - 1), IC<kb>{}); else chain(u & (MF_NST - 1), IC<kb>{}, IC<0>{}, IC<8>{}); }
             if constexpr (PD != 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
             end_of_unit(u);
             ++u;
@@ -376,7 +509,15 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
         if (tile + 1 < ntiles) init_acc(tile + 1);
     }
 
-    if (h == 0) {
+    if constexpr (M16) {
+        if (g4 == 0) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                cnts[(int64_t)slice * nq_pad + qbase + 16 * cb + l15] = cnt2[cb];
+                thrs[(int64_t)slice * nq_pad + qbase + 16 * cb + l15] = thr2[cb];
+            }
+        }
+    } else if (h == 0) {
         cnts[(int64_t)slice * nq_pad + qglob] = cnt;
         thrs[(int64_t)slice * nq_pad + qglob] = thr;
     }
@@ -650,6 +791,10 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
     }
     const int ngroups = (ns + spg_max - 1) / spg_max;
     plan->pd = (nqt <= 2) ? 3 : 2;
+    // MFMA shape: 16x16x32 in the MFMA-bound variant (+8.6 % at 100M x 384 on one device: same
+    // cycles, higher sustained clock); MI_MFMA_M16=0 selects 32x32x16 for A/B runs
+    plan->m16 = (plan->pd == 2) ? 1 : 0;
+    if (const char* e = getenv("MI_MFMA_M16")) plan->m16 = (atoi(e) != 0 && plan->pd == 2) ? 1 : 0;
     if (const char* e = getenv("MI_MFMA_PD")) { const int v = atoi(e); if (v == 2 || v == 3) plan->pd = v; }
     plan->kprime = kp;
     plan->cap = cap;
@@ -664,14 +809,14 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
     return MI_OK;
 }
 
-template <int NKB, int KP, bool L2, int PD>
+template <int NKB, int KP, bool L2, int PD, bool M16>
 static void launch_scan(hipStream_t st, const mi_mfma_plan* p, const uint16_t* rows, const float* xx, int64_t n,
                         int d_pad, const uint16_t* q_bf16, int nq, uint64_t* lists, int32_t* cnts, float* thrs, uint32_t* gthr)
 {
     const int qtile = 32 * mf_waves(NKB);
     const int nqt = p->nq_pad / qtile;
     const unsigned grid = (unsigned)(nqt * p->nslices);
-    mfma_scan_kernel<NKB, KP, L2, PD><<<grid, 64 * mf_waves(NKB), 0, st>>>(rows, xx, n, d_pad * 2, q_bf16, nq, p->nq_pad, nqt,
+    mfma_scan_kernel<NKB, KP, L2, PD, M16><<<grid, 64 * mf_waves(NKB), 0, st>>>(rows, xx, n, d_pad * 2, q_bf16, nq, p->nq_pad, nqt,
                                                                        p->slice_rows, lists, cnts, thrs, gthr);
 }
 
@@ -683,10 +828,14 @@ int mi_launch_mfma_scan(hipStream_t st, const mi_mfma_plan* p, int metric, const
     const bool l2 = metric == MI_METRIC_L2;
 #define MF_CASE(NKB_, KP_) \
     if (nkb == NKB_ && p->kprime == KP_) { \
-        if (l2 && p->pd == 3) launch_scan<NKB_, KP_, true, 3>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
-        else if (l2) launch_scan<NKB_, KP_, true, 2>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
-        else if (p->pd == 3) launch_scan<NKB_, KP_, false, 3>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
-        else launch_scan<NKB_, KP_, false, 2>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+        if (p->m16) { \
+            if (l2) launch_scan<NKB_, KP_, true, 2, true>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+            else launch_scan<NKB_, KP_, false, 2, true>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+        } \
+        else if (l2 && p->pd == 3) launch_scan<NKB_, KP_, true, 3, false>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+        else if (l2) launch_scan<NKB_, KP_, true, 2, false>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+        else if (p->pd == 3) launch_scan<NKB_, KP_, false, 3, false>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
+        else launch_scan<NKB_, KP_, false, 2, false>(st, p, rows, xx, n, d_pad, q_bf16, (int)nq, lists, cnts, thrs, gthr); \
         MI_HIP(hipGetLastError()); return MI_OK; }
     MF_CASE(1, 16) MF_CASE(1, 32) MF_CASE(1, 128)
     MF_CASE(3, 16) MF_CASE(3, 32) MF_CASE(3, 128)
@@ -712,14 +861,10 @@ int mi_launch_mfma_finish(hipStream_t st, const mi_mfma_plan* p, int metric, con
     if (nq <= 0) return MI_OK;
     const size_t smem = (size_t)MF_PH2_MAX * 8 + (size_t)MF_SORT_MAX * 8 + (size_t)d_pad * 4 + (size_t)(p->spg + 1) * 4;
     if (smem > 150 * 1024) { mi_set_error("mfma finish: d_pad %d too large", d_pad); return MI_ERR_UNSUPPORTED; }
-    static bool attr_set = false;
-    if (!attr_set) {
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_finish_kernel<uint16_t>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_finish_kernel<float>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    // per call: the attribute is per device, and callers arrive from several threads
+    MI_HIP(hipFuncSetAttribute(canon_dtype == MI_DTYPE_BF16 ? reinterpret_cast<const void*>(mfma_finish_kernel<uint16_t>)
+                                                              : reinterpret_cast<const void*>(mfma_finish_kernel<float>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     const dim3 grid((unsigned)nq, (unsigned)p->ngroups);
     if (canon_dtype == MI_DTYPE_BF16)
         mfma_finish_kernel<uint16_t><<<grid, 256, smem, st>>>(metric, (const uint16_t*)canon_rows, xx, max_xx, d_pad, q_canon, qq,
