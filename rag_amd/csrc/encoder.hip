@@ -18,6 +18,9 @@
 // max/sum, MFMA accumulation, pooling) is fp32.  Tolerance vs the fp32 CPU oracle: 1 - cos <= 1e-3
 // (BASELINE.json north_star), measured ~1e-5 in tests/test_encoder_gpu.py.
 #include <float.h>
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -25,6 +28,12 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int V> using IC = std::integral_constant<int, V>;
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(IC<I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
@@ -312,6 +321,209 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const uint16_t* __res
             }
         }
         if (mi == 0) __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- weight-stationary GEMM, K = 384
+// C[M][N] = A[M][384] * W[N][384]^T (+ epilogue) for the three projections whose reduction is the
+// hidden size (QKV, FFN1, attention output).  The 128x128 tile kernel above re-reads both
+// operands from L2 for every tile (64 flop per LDS-staged byte; measured: matrix pipe 33 % busy,
+// 12 TB/s of L2 traffic).  This one is the flat-search scan turned into a GEMM:
+//   * a workgroup of 8 waves owns 256 output columns; wave w keeps the W fragments of its 32
+//     columns x 384 in registers (96 VGPRs) for its whole life;
+//   * activation rows stream through LDS once per 256 columns, in units of 128 rows x 256 B,
+//     LDS-DMA, double-buffered, source-side swizzle — the scan's image, so 256 flop per byte;
+//   * v_mfma_f32_16x16x32_bf16 with the W fragment as the A operand: a lane owns one output row
+//     (lane & 15) and four consecutive columns per accumulator block, so bias / GELU are
+//     per-register and the tile is parked in LDS and leaves as whole 512-B row segments;
+//   * one workgroup per CU, placed by hand: the 32 workgroups of an XCD (blockIdx % 8) form
+//     floor(32 / G) row chunks x G column groups; the G groups of a chunk walk the same row
+//     tiles in step, so each activation tile comes from HBM once per XCD.
+// Waves whose columns lie beyond N only help with the loads and stores.
+#define WS_TILE_R 128
+#define WS_STAGE (WS_TILE_R * 256)
+#define WS_PARK_OFF (2 * WS_STAGE)
+#define WS_TS16 528                 // parked bf16 row: 256 columns + 8 pad
+#define WS_TS32 1056                // parked fp32 row (64 rows at a time)
+#define WS_LDS_BYTES (WS_PARK_OFF + 128 * WS_TS16)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+        const float* __restrict__ bias, const uint16_t* __restrict__ resid, uint16_t* __restrict__ C,
+        int M, int N, int n_groups, int n_chunks)
+{
+    constexpr int K = 384, NKB = 3, PPW = 4;
+    static_assert(128 * WS_TS16 == 64 * WS_TS32, "one park buffer for both forms");
+    __shared__ __attribute__((aligned(1024))) char lds[WS_LDS_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+
+    // placement: XCD = blockIdx % 8 (round-robin dispatch); k-th workgroup of the XCD
+    const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
+    if (kx >= n_groups * n_chunks) return;                         // spare CUs of this XCD
+    const int chunk = kx / n_groups, ng = kx % n_groups;
+    const int m_tiles = (M + WS_TILE_R - 1) / WS_TILE_R;
+    const int tiles_x = (m_tiles - xcd + 7) / 8;                   // row tiles xcd, xcd + 8, ... of this XCD
+    const int t_lo = (int)((int64_t)tiles_x * chunk / n_chunks), t_hi = (int)((int64_t)tiles_x * (chunk + 1) / n_chunks);
+    const int ntiles = t_hi - t_lo;
+    const int nunits = ntiles * NKB;
+    const int n0 = ng * 256;
+    const bool active = n0 + wave * 32 < N;                        // wave-uniform (N is a multiple of 32)
+
+    // ---- stationary W fragments: lane (l15, g4) holds rows n0 + 32 w + 16 nb + l15, k = 32 s + 8 g4 + j
+    bf16x8 wq[12][2];
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < 12; ++s)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                wq[s][nb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
+                    W + (int64_t)(n0 + wave * 32 + 16 * nb + l15) * K + 32 * s + 8 * g4));
+#pragma unroll
+        for (int s = 0; s < 12; ++s) asm volatile("" :: "v"(wq[s][0]), "v"(wq[s][1]));   // retire before the loop (see search_mfma.hip)
+    }
+    float4 bv[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if (active) {
+        bv[0] = *reinterpret_cast<const float4*>(bias + n0 + wave * 32 + 4 * g4);
+        bv[1] = *reinterpret_cast<const float4*>(bias + n0 + wave * 32 + 16 + 4 * g4);
+    }
+
+    // ---- LDS-DMA: wave w issues pieces 4w..4w+3 of a unit (4 rows x 256 B each)
+    const int lr = lane >> 4, lt = lane & 15;
+    const unsigned sw0 = (unsigned)(lt ^ lr) << 4;
+    auto tile_row0 = [&](int tl) { return (int64_t)(8 * (t_lo + tl) + xcd) * WS_TILE_R; };
+    const char* Ab = reinterpret_cast<const char*>(A) + (int64_t)(4 * wave * PPW + lr) * (K * 2);
+    auto issue_unit = [&](int tl, int kb, int buf) __attribute__((always_inline)) {
+        const int64_t off = tile_row0(tl) * (K * 2) + kb * 256;                  // rows past M: workspace slack, never stored
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ab + (off + (int64_t)i * 4 * (K * 2)) + (sw0 ^ ((i & 3) << 6))),
+                (lds_ptr_t)(lds + buf * WS_STAGE + (wave * PPW + i) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[8][2];                                               // [16-row block of the tile][16-column block of the wave]
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    auto chain = [&](int buf, auto KBc) __attribute__((always_inline)) {
+        constexpr int KB = decltype(KBc)::value;
+        const unsigned cur = (lds_base + buf * WS_STAGE + l15 * 256) | ((unsigned)(g4 ^ l15) << 4);
+        bf16x8 a[2][4];
+        auto rd = [&](bf16x8 (&f)[4], int grp) __attribute__((always_inline)) {
+            const unsigned ad = cur ^ ((unsigned)(grp >> 1) << 6);
+            if (grp & 1)
+                asm volatile("ds_read_b128 %0, %4 offset:16384\n\tds_read_b128 %1, %4 offset:20480\n\t"
+                             "ds_read_b128 %2, %4 offset:24576\n\tds_read_b128 %3, %4 offset:28672"
+                             : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]) : "v"(ad));
+            else
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\t"
+                             "ds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %4 offset:12288"
+                             : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]) : "v"(ad));
+        };
+        rd(a[0], 0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t < 7) {
+                rd(a[(t + 1) & 1], t + 1);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[t & 1][0]), "+v"(a[t & 1][1]), "+v"(a[t & 1][2]), "+v"(a[t & 1][3]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[t & 1][0]), "+v"(a[t & 1][1]), "+v"(a[t & 1][2]), "+v"(a[t & 1][3]));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[4 * (t & 1) + r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        wq[KB * 4 + (t >> 1)][nb], a[t & 1][r], acc[4 * (t & 1) + r][nb], 0, 0, 0);
+        }
+    };
+
+    // ---- epilogue of one tile: the lane holds, for row 16 mb + l15, columns 32 w + 16 nb + 4 g4 + (0..3)
+    char* park = lds + WS_PARK_OFF;
+    auto epilogue = [&](int tl) __attribute__((always_inline)) {
+        const int64_t m_base = tile_row0(tl);
+        const int r0 = threadIdx.x >> 5, ch = threadIdx.x & 31;      // store phase: row r0 + 16 p, 16-B chunk ch (8 columns)
+        const bool col_ok = n0 + 8 * ch < N;
+        if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {                   // fp32 park, 64 rows at a time: one rounding, after the residual
+                if (active) {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            const f32x4 v = acc[4 * half + mb][nb];
+                            *reinterpret_cast<float4*>(park + (16 * mb + l15) * WS_TS32 + (wave * 32 + 16 * nb + 4 * g4) * 4) =
+                                make_float4(v[0] + bv[nb].x, v[1] + bv[nb].y, v[2] + bv[nb].z, v[3] + bv[nb].w);
+                        }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int r = r0 + 16 * p;
+                    const int64_t m = m_base + 64 * half + r;
+                    if (m < M && col_ok) {
+                        const float4 x0 = *reinterpret_cast<const float4*>(park + r * WS_TS32 + ch * 32);
+                        const float4 x1 = *reinterpret_cast<const float4*>(park + r * WS_TS32 + ch * 32 + 16);
+                        const uint4 rv = *reinterpret_cast<const uint4*>(resid + m * N + n0 + 8 * ch);
+                        uint4 o;
+                        o.x = pack2(x0.x + __builtin_bit_cast(float, rv.x << 16), x0.y + __builtin_bit_cast(float, rv.x & 0xFFFF0000u));
+                        o.y = pack2(x0.z + __builtin_bit_cast(float, rv.y << 16), x0.w + __builtin_bit_cast(float, rv.y & 0xFFFF0000u));
+                        o.z = pack2(x1.x + __builtin_bit_cast(float, rv.z << 16), x1.y + __builtin_bit_cast(float, rv.z & 0xFFFF0000u));
+                        o.w = pack2(x1.z + __builtin_bit_cast(float, rv.w << 16), x1.w + __builtin_bit_cast(float, rv.w & 0xFFFF0000u));
+                        *reinterpret_cast<uint4*>(C + m * N + n0 + 8 * ch) = o;
+                    }
+                }
+                __syncthreads();
+            }
+        } else {
+            if (active) {
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const f32x4 v = acc[mb][nb];
+                        float v0 = v[0] + bv[nb].x, v1 = v[1] + bv[nb].y, v2 = v[2] + bv[nb].z, v3 = v[3] + bv[nb].w;
+                        if constexpr (EPI == EPI_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                        *reinterpret_cast<uint2*>(park + (16 * mb + l15) * WS_TS16 + (wave * 32 + 16 * nb + 4 * g4) * 2) =
+                            make_uint2(pack2(v0, v1), pack2(v2, v3));
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int r = r0 + 16 * p;
+                const int64_t m = m_base + r;
+                if (m < M && col_ok)
+                    *reinterpret_cast<uint4*>(C + m * N + n0 + 8 * ch) = *reinterpret_cast<const uint4*>(park + r * WS_TS16 + ch * 16);
+            }
+            // the next park write is three unit barriers away
+        }
+    };
+
+    // ---- main loop: double-buffered units, one barrier each (the scan's PD = 1 form)
+    if (nunits > 0) {
+        issue_unit(0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    int u = 0;
+    for (int tl = 0; tl < ntiles; ++tl) {
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[mb][nb][i] = 0.0f;
+        static_for<NKB>([&](auto KBc) __attribute__((always_inline)) {
+            constexpr int kb = decltype(KBc)::value;
+            if (u + 1 < nunits) issue_unit(tl + (kb + 1) / NKB, (kb + 1) % NKB, (u + 1) & 1);
+            if (active) chain(u & 1, IC<kb>{});
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            ++u;
+        });
+        epilogue(tl);
     }
 }
 
@@ -661,10 +873,29 @@ extern "C" void mi_encoder_destroy(mi_encoder* e)
     if (prev >= 0) (void)hipSetDevice(prev);
 }
 
+// K = 384 projections on enough rows to fill the chip: the weight-stationary kernel
+template <int EPI>
+static bool launch_gemm_ws(hipStream_t st, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* resid,
+                           uint16_t* C, int M, int N, int K)
+{
+    static const bool off = getenv("MI_GEMM_WS") && atoi(getenv("MI_GEMM_WS")) == 0;
+    // N = 384 (attention output) fills only 1.5 column groups: measured slower than the tile kernel
+    if (off || K != 384 || N % 32 != 0 || N < 512 || M < 16384) return false;
+    const int n_groups = (N + 255) / 256;
+    if (n_groups > 32) return false;
+    const int m_tiles = (M + WS_TILE_R - 1) / WS_TILE_R;
+    int n_chunks = 32 / n_groups;
+    if (n_chunks > m_tiles / 8) n_chunks = m_tiles / 8;
+    if (n_chunks < 1) return false;
+    gemm_ws_kernel<EPI><<<256, 512, 0, st>>>(A, W, bias, resid, C, M, N, n_groups, n_chunks);
+    return true;
+}
+
 template <int EPI>
 static void launch_gemm(hipStream_t st, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* resid,
                         uint16_t* C, int M, int N, int K)
 {
+    if (launch_gemm_ws<EPI>(st, A, W, bias, resid, C, M, N, K)) return;
     const int n_tiles = N / GM_BN, m_tiles = (M + GM_BM - 1) / GM_BM;
     const unsigned grid = (unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles);
     gemm_bf16_kernel<EPI><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K, n_tiles, m_tiles);
@@ -678,7 +909,8 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
     const int64_t T = B * L;
     MI_REQUIRE(T < ((int64_t)1 << 31) / 16, "encode: too many tokens in one call (%lld)", (long long)T);
     // workspace: h, tmp, ctx [T][H]; qkv [T][3H]; mid [T][I]  (bf16)
-    const size_t need = (size_t)T * ((size_t)3 * H + 3 * H + I) * sizeof(uint16_t);
+    // + 128 rows of slack: the weight-stationary GEMM streams whole 128-row tiles of its A operand
+    const size_t need = ((size_t)T * ((size_t)3 * H + 3 * H + I) + (size_t)128 * I) * sizeof(uint16_t);
     if (need > e->ws_bytes) {
         if (e->ws) { MI_HIP(hipStreamSynchronize(st)); (void)hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0; }
         hipError_t er = hipMalloc(&e->ws, need);

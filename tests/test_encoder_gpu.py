@@ -99,3 +99,28 @@ def test_device_pointer_variant_matches_host_variant():
     Et = enc.encode_ids_torch(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda())
     torch.cuda.synchronize()
     np.testing.assert_array_equal(E, Et.cpu().numpy())
+
+
+def test_large_batch_takes_the_weight_stationary_gemm(oracle_mod):
+    """>= 16384 tokens per pass: the K = 384 projections run on gemm_ws_kernel (ragged token count,
+    so the last row tile is partial); a sample of sequences is checked against the oracle."""
+    from rag_amd._capi import BertConfig
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import random_blob
+    cfg = BertConfig(vocab_size=2000, hidden_size=384, num_hidden_layers=2, num_attention_heads=12,
+                     intermediate_size=1536, max_position_embeddings=512, type_vocab_size=2,
+                     layer_norm_eps=1e-12, normalize=1)
+    blob = random_blob(cfg, seed=3, init_range=0.05)
+    rng = np.random.default_rng(4)
+    B, L = 131, 200                                       # 26200 tokens: 204 full row tiles + 88 rows
+    ids = rng.integers(0, 2000, size=(B, L)).astype(np.int32)
+    mask = np.ones((B, L), dtype=np.int32)
+    for b in range(0, B, 7):
+        mask[b, rng.integers(20, L):] = 0
+    E = Encoder(cfg, blob).encode_ids(ids, mask)
+    ocfg = oracle_mod.BertConfig(*[getattr(cfg, f) for f, _ in BertConfig._fields_])
+    sel = [0, 1, 7, 64, 65, 129, 130]
+    Eo = oracle_mod.encode(ocfg, blob, ids[sel], mask[sel])
+    cos = (E[sel] * Eo).sum(1) / (np.linalg.norm(E[sel], axis=1) * np.linalg.norm(Eo, axis=1))
+    assert np.all(1.0 - cos < 1e-3), 1.0 - cos
+    assert np.all(np.isfinite(E))
