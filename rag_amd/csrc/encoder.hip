@@ -527,6 +527,190 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
     }
 }
 
+// ---------------------------------------------------------------- row-complete GEMM + bias + residual + LayerNorm, N = 384
+// out[M][384] = LayerNorm(A[M][K] * W[384][K]^T + bias + resid) * gamma + beta   (modeling_bert.py:289-293, :347-351)
+// for the attention output (K = 384) and FFN output (K = 1536) projections.  One workgroup of
+// 8 waves owns 128 COMPLETE rows (4 row groups x 2 column halves: a wave holds 32 rows x 192
+// columns = 24 accumulator blocks of 16x16), so the LayerNorm statistics never leave the
+// workgroup, the separate LN kernel and the [tokens][384] round trip through HBM disappear, and
+// the activation tile is staged once per 384 columns instead of once per 128 (96 flop per staged
+// byte instead of 64).  v_mfma_f32_16x16x32_bf16 with the W fragment as the A operand: a lane owns
+// row (lane & 15) of a block and four consecutive columns, so bias / gamma / beta are float4 and
+// the finished tile is parked in LDS and leaves as whole 768-B rows.  Stages of 64 k (A 16 KB +
+// W 48 KB), LDS-DMA, double-buffered, 128-B rows swizzled as in gemm_bf16_kernel.
+// `out` may alias `resid`: a workgroup reads and writes only its own rows.
+#define LN_N 384
+#define LN_STAGE (512 * 128)                 // 128 A rows + 384 W rows, 128 B each
+#define LN_TS 784                            // parked bf16 row: 384 columns + 8 pad
+
+__global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+        const float* __restrict__ bias, const uint16_t* __restrict__ resid, const float* __restrict__ gamma,
+        const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int K)
+{
+    __shared__ __attribute__((aligned(1024))) char lds[2 * LN_STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    // last rows first: the producer kernel wrote them last, so they are the part of A still in the Infinity Cache
+    const int m0 = (int)(gridDim.x - 1 - blockIdx.x) * 128;
+
+    // LDS-DMA: 16 A pieces + 48 W pieces per stage (8 rows x 128 B each); wave w: A pieces 2w, 2w+1, W pieces 6w..6w+5
+    const int lr = lane >> 3, lt = lane & 7;
+    const int64_t rowbytes = (int64_t)K * 2;
+    const char* src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int p = (i < 2) ? 2 * wave + i : 16 + 6 * wave + (i - 2);          // piece = 8 rows of the stage image
+        const int r = 8 * p + lr;                                                // stage row: 0..127 A, 128..511 W
+        const int sw = (lt ^ ((r >> 1) & 7)) << 4;
+        if (i < 2) { int ra = m0 + r; if (ra > M - 1) ra = M - 1; src[i] = reinterpret_cast<const char*>(A) + ra * rowbytes + sw; }
+        else src[i] = reinterpret_cast<const char*>(W) + (int64_t)(r - 128) * rowbytes + sw;
+    }
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = (i < 2) ? 2 * wave + i : 16 + 6 * wave + (i - 2);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[i] + kt * 128), (lds_ptr_t)(lds + buf * LN_STAGE + p * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[2][12];                                  // [16-row block][16-column block]
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[mb][nb][i] = 0.0f;
+
+    // fragment addresses: stage row r, 16-B chunk (4 s + g4) ^ ((r >> 1) & 7); r = base + l15 with base a
+    // multiple of 16, so (r >> 1) & 7 = l15 >> 1 and step s is one xor with a constant
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const unsigned fsw = (unsigned)(g4 ^ (l15 >> 1)) << 4;
+    const unsigned a_adr = lds_base + (unsigned)((32 * wm + l15) * 128) + fsw;            // + mb * 2048
+    const unsigned w_adr = lds_base + (unsigned)((128 + 192 * wn + l15) * 128) + fsw;     // + nb * 2048
+
+    const int nkt = K / 64;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
+        const unsigned ab = a_adr + buf * LN_STAGE, wb = w_adr + buf * LN_STAGE;
+        // 6 groups per stage: (k-step s, column group j) -> 4 W fragments, 8 MFMAs; the two A fragments
+        // of a k-step arrive with its group 0.  One group is read ahead of the one being multiplied.
+        bf16x8 af[2][2], wf[2][4];
+        auto rd_w = [&](bf16x8 (&f)[4], int s, int j) __attribute__((always_inline)) {
+            const unsigned ad = (wb + j * 8192) ^ ((unsigned)s << 6);
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\t"
+                         "ds_read_b128 %2, %4 offset:4096\n\tds_read_b128 %3, %4 offset:6144"
+                         : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]) : "v"(ad));
+        };
+        auto rd_a = [&](bf16x8 (&f)[2], int s) __attribute__((always_inline)) {
+            const unsigned ad = ab ^ ((unsigned)s << 6);
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:2048" : "=&v"(f[0]), "=&v"(f[1]) : "v"(ad));
+        };
+        rd_a(af[0], 0);
+        rd_w(wf[0], 0, 0);
+#pragma unroll
+        for (int gq = 0; gq < 6; ++gq) {
+            const int s = gq / 3, j = gq % 3;
+            if (gq < 5) {
+                const int s1 = (gq + 1) / 3, j1 = (gq + 1) % 3;
+                if (j1 == 0) {
+                    rd_a(af[s1 & 1], s1);
+                    rd_w(wf[(gq + 1) & 1], s1, j1);
+                    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wf[gq & 1][0]), "+v"(wf[gq & 1][1]), "+v"(wf[gq & 1][2]), "+v"(wf[gq & 1][3]),
+                                 "+v"(af[s & 1][0]), "+v"(af[s & 1][1]));
+                } else {
+                    rd_w(wf[(gq + 1) & 1], s1, j1);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[gq & 1][0]), "+v"(wf[gq & 1][1]), "+v"(wf[gq & 1][2]), "+v"(wf[gq & 1][3]),
+                                 "+v"(af[s & 1][0]), "+v"(af[s & 1][1]));
+                }
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[gq & 1][0]), "+v"(wf[gq & 1][1]), "+v"(wf[gq & 1][2]), "+v"(wf[gq & 1][3]),
+                             "+v"(af[s & 1][0]), "+v"(af[s & 1][1]));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    acc[mb][4 * j + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[gq & 1][q], af[s & 1][mb], acc[mb][4 * j + q], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue.  The lane holds, for rows m = m0 + 32 wm + 16 mb + l15, columns 192 wn + 16 nb + 4 g4 + (0..3).
+    float* rs = reinterpret_cast<float*>(lds);                 // [2 passes][2 column halves][128 rows] row sums
+    char* park = lds + 4096;
+    float mean[2], inv[2];
+    // bias + residual (8-byte loads: 4 consecutive columns of the lane's row), row sum
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int ml = 32 * wm + 16 * mb + l15;
+        int m = m0 + ml; if (m > M - 1) m = M - 1;
+        float sum = 0.0f;
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb) {
+            const int n = 192 * wn + 16 * nb + 4 * g4;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+            const uint2 rv = *reinterpret_cast<const uint2*>(resid + (int64_t)m * LN_N + n);
+            acc[mb][nb][0] += bv.x + __builtin_bit_cast(float, rv.x << 16);
+            acc[mb][nb][1] += bv.y + __builtin_bit_cast(float, rv.x & 0xFFFF0000u);
+            acc[mb][nb][2] += bv.z + __builtin_bit_cast(float, rv.y << 16);
+            acc[mb][nb][3] += bv.w + __builtin_bit_cast(float, rv.y & 0xFFFF0000u);
+            sum += (acc[mb][nb][0] + acc[mb][nb][1]) + (acc[mb][nb][2] + acc[mb][nb][3]);
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (g4 == 0) rs[wn * 128 + ml] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int ml = 32 * wm + 16 * mb + l15;
+        mean[mb] = (rs[ml] + rs[128 + ml]) * (1.0f / LN_N);
+        float sq = 0.0f;
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float dlt = acc[mb][nb][i] - mean[mb]; sq += dlt * dlt; }
+        sq += __shfl_xor(sq, 16, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        if (g4 == 0) rs[256 + wn * 128 + ml] = sq;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int ml = 32 * wm + 16 * mb + l15;
+        inv[mb] = 1.0f / sqrtf((rs[256 + ml] + rs[384 + ml]) * (1.0f / LN_N) + eps);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 12; ++nb) {
+        const int n = 192 * wn + 16 * nb + 4 * g4;
+        const float4 gv = *reinterpret_cast<const float4*>(gamma + n);
+        const float4 be = *reinterpret_cast<const float4*>(beta + n);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int ml = 32 * wm + 16 * mb + l15;
+            const float y0 = (acc[mb][nb][0] - mean[mb]) * inv[mb] * gv.x + be.x, y1 = (acc[mb][nb][1] - mean[mb]) * inv[mb] * gv.y + be.y;
+            const float y2 = (acc[mb][nb][2] - mean[mb]) * inv[mb] * gv.z + be.z, y3 = (acc[mb][nb][3] - mean[mb]) * inv[mb] * gv.w + be.w;
+            *reinterpret_cast<uint2*>(park + ml * LN_TS + n * 2) = make_uint2(pack2(y0, y1), pack2(y2, y3));
+        }
+    }
+    __syncthreads();
+    // whole 768-B rows out: thread t takes 16-B chunk t % 48 of rows t / 48 + 10 p (480 of the 512 threads)
+    if (threadIdx.x < 480) {
+        const int r0 = threadIdx.x / 48, ch = threadIdx.x % 48;
+        for (int r = r0; r < 128; r += 10) {
+            const int m = m0 + r;
+            if (m < M) *reinterpret_cast<uint4*>(out + (int64_t)m * LN_N + 8 * ch) = *reinterpret_cast<const uint4*>(park + r * LN_TS + ch * 16);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- attention (head size 32)
 // One workgroup per (head, sequence, 256-query block); wave w owns 64 queries = 2 lane blocks.
 // S^T = K Q^T (keys on accumulator rows, the query on the lane), so max/sum over keys are
@@ -929,19 +1113,30 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
     if (attn_smem > 96 * 1024) { mi_set_error("encode: sequence length %d too long for the attention kernel", L); return MI_ERR_UNSUPPORTED; }
     const float scale_log2e = (1.0f / sqrtf(32.0f)) * 1.4426950408889634f;
 
+    // hidden size 384: the two N = 384 projections run fused with their LayerNorm (MI_GEMM_LN=0: separate kernels)
+    static const bool ln_off = getenv("MI_GEMM_LN") && atoi(getenv("MI_GEMM_LN")) == 0;
+    const bool fused_ln = !ln_off && H == LN_N && I % 64 == 0;
     MI_HIP(hipEventRecord(e->ev0, st));
     if (H <= 384) embed_ln_kernel<6><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     else embed_ln_kernel<16><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     for (const LayerW& lw : e->layers) {
         launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H);
         attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, scale_log2e);
-        launch_gemm<EPI_RESID>(st, ctx, lw.Wo, lw.bo, h, tmp, (int)T, H, H);
-        if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
-        else add_ln_kernel<2><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
+        if (fused_ln) {
+            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(ctx, lw.Wo, lw.bo, h, lw.g1, lw.b1, c.layer_norm_eps, h, (int)T, H);
+        } else {
+            launch_gemm<EPI_RESID>(st, ctx, lw.Wo, lw.bo, h, tmp, (int)T, H, H);
+            if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
+            else add_ln_kernel<2><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
+        }
         launch_gemm<EPI_GELU>(st, h, lw.Wi, lw.bi, nullptr, mid, (int)T, I, H);
-        launch_gemm<EPI_RESID>(st, mid, lw.Wd, lw.bd, h, tmp, (int)T, H, I);
-        if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
-        else add_ln_kernel<2><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
+        if (fused_ln) {
+            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(mid, lw.Wd, lw.bd, h, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I);
+        } else {
+            launch_gemm<EPI_RESID>(st, mid, lw.Wd, lw.bd, h, tmp, (int)T, H, I);
+            if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
+            else add_ln_kernel<2><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
+        }
     }
     if (H <= 512) pool_kernel<1><<<(unsigned)B, 256, 0, st>>>(h, mask, L, H, c.normalize, out);
     else pool_kernel<2><<<(unsigned)B, 256, 0, st>>>(h, mask, L, H, c.normalize, out);
