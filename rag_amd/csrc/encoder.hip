@@ -76,7 +76,7 @@ __device__ __forceinline__ float wave_sum(float v)
 
 // ---------------------------------------------------------------- embeddings + LayerNorm
 // One wave per token; lane holds columns lane, lane+64, ... (H <= 1024).
-template <int MAXE>
+template <int NCH>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, int64_t T, int L, int H, int vocab,
         const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type0,
         const float* __restrict__ gamma, const float* __restrict__ beta, float eps, uint16_t* __restrict__ out)
@@ -87,23 +87,48 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
     int id = ids[tok];
     if (id < 0 || id >= vocab) id = 0;              // ids are validated on the host; never index out of the table
     const int p = (int)(tok % L);
-    float x[MAXE];
+    float x[NCH][8];
     float s = 0.0f;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-        const int c = lane + 64 * e;
-        x[e] = (c < H) ? (word[(int64_t)id * H + c] + type0[c]) + pos[(int64_t)p * H + c] : 0.0f;
-        s += x[e];
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 8 * lane + 512 * c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[c][e] = 0.0f;
+        if (col < H) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 w = *reinterpret_cast<const float4*>(word + (int64_t)id * H + col + 4 * q);
+                const float4 t0 = *reinterpret_cast<const float4*>(type0 + col + 4 * q);
+                const float4 ps = *reinterpret_cast<const float4*>(pos + (int64_t)p * H + col + 4 * q);
+                x[c][4 * q + 0] = (w.x + t0.x) + ps.x; x[c][4 * q + 1] = (w.y + t0.y) + ps.y;
+                x[c][4 * q + 2] = (w.z + t0.z) + ps.z; x[c][4 * q + 3] = (w.w + t0.w) + ps.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += x[c][e];
+        }
     }
     const float mean = wave_sum(s) / (float)H;
     float v = 0.0f;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) { const int c = lane + 64 * e; const float dlt = (c < H) ? x[e] - mean : 0.0f; v += dlt * dlt; }
+    for (int c = 0; c < NCH; ++c)
+        if (8 * lane + 512 * c < H) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dlt = x[c][e] - mean; v += dlt * dlt; }
+        }
     const float inv = 1.0f / sqrtf(wave_sum(v) / (float)H + eps);
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-        const int c = lane + 64 * e;
-        if (c < H) out[tok * H + c] = f2bf((x[e] - mean) * inv * gamma[c] + beta[c]);
+    for (int c = 0; c < NCH; ++c) {
+        const int col = 8 * lane + 512 * c;
+        if (col < H) {
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma + col), g1 = *reinterpret_cast<const float4*>(gamma + col + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(beta + col), b1 = *reinterpret_cast<const float4*>(beta + col + 4);
+            uint4 o;
+            o.x = pack2((x[c][0] - mean) * inv * g0.x + b0.x, (x[c][1] - mean) * inv * g0.y + b0.y);
+            o.y = pack2((x[c][2] - mean) * inv * g0.z + b0.z, (x[c][3] - mean) * inv * g0.w + b0.w);
+            o.z = pack2((x[c][4] - mean) * inv * g1.x + b1.x, (x[c][5] - mean) * inv * g1.y + b1.y);
+            o.w = pack2((x[c][6] - mean) * inv * g1.z + b1.z, (x[c][7] - mean) * inv * g1.w + b1.w);
+            *reinterpret_cast<uint4*>(out + tok * H + col) = o;
+        }
     }
 }
 
@@ -852,14 +877,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
 }
 
 // ---------------------------------------------------------------- masked mean pool + L2 normalise
-// One workgroup per sequence; wave w sums tokens i = w (mod 4), lane l the 8 columns
-// [8 l + 512 c, +8); the four partial sums meet in LDS.  fp32 throughout.
+// One workgroup of 16 waves per sequence; wave w sums tokens i = w (mod 16), lane l the 8 columns
+// [8 l + 512 c, +8); the partial sums meet in LDS.  fp32 throughout.
+#define POOL_WAVES 16
 template <int NCH>
-__global__ __launch_bounds__(256) void pool_kernel(const uint16_t* __restrict__ hid, const int32_t* __restrict__ mask,
+__global__ __launch_bounds__(64 * POOL_WAVES) void pool_kernel(const uint16_t* __restrict__ hid, const int32_t* __restrict__ mask,
         int L, int H, int normalize, float* __restrict__ out)
 {
-    __shared__ float part[4][NCH * 512];
-    __shared__ float red[4];
+    __shared__ float part[POOL_WAVES][NCH * 512];
+    __shared__ float red[POOL_WAVES];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t b = blockIdx.x;
     float acc[NCH][8];
@@ -868,7 +894,7 @@ __global__ __launch_bounds__(256) void pool_kernel(const uint16_t* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[c][e] = 0.0f;
     int cnt = 0;
-    for (int i = wave; i < L; i += 4) {
+    for (int i = wave; i < L; i += POOL_WAVES) {
         if (mask[b * L + i] == 0) continue;      // wave-uniform
         ++cnt;
         const uint16_t* row = hid + (b * L + i) * H;
@@ -892,24 +918,37 @@ __global__ __launch_bounds__(256) void pool_kernel(const uint16_t* __restrict__ 
         for (int e = 0; e < 8; ++e) part[wave][512 * c + 8 * lane + e] = acc[c][e];
     if (lane == 0) red[wave] = (float)cnt;
     __syncthreads();
-    const float den = fmaxf(red[0] + red[1] + red[2] + red[3], 1e-9f);
+    float cnt_all = 0.0f;
+#pragma unroll
+    for (int w = 0; w < POOL_WAVES; ++w) cnt_all += red[w];
+    const float den = fmaxf(cnt_all, 1e-9f);
     __syncthreads();
+    // threads 0 .. 255 finish: column t + 256 e
     float v[2 * NCH];
     float ss = 0.0f;
+    if (t < 256) {
 #pragma unroll
-    for (int e = 0; e < 2 * NCH; ++e) {
-        const int col = t + 256 * e;
-        v[e] = (col < H) ? (part[0][col] + part[1][col] + part[2][col] + part[3][col]) / den : 0.0f;
-        ss += v[e] * v[e];
+        for (int e = 0; e < 2 * NCH; ++e) {
+            const int col = t + 256 * e;
+            float a = 0.0f;
+            if (col < H) {
+#pragma unroll
+                for (int w = 0; w < POOL_WAVES; ++w) a += part[w][col];
+            }
+            v[e] = a / den;
+            ss += v[e] * v[e];
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
     }
-    ss = wave_sum(ss);
-    if (lane == 0) red[wave] = ss;
     __syncthreads();
-    const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
+    if (t < 256) {
+        const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
 #pragma unroll
-    for (int e = 0; e < 2 * NCH; ++e) {
-        const int col = t + 256 * e;
-        if (col < H) out[b * H + col] = normalize ? v[e] / nrm : v[e];
+        for (int e = 0; e < 2 * NCH; ++e) {
+            const int col = t + 256 * e;
+            if (col < H) out[b * H + col] = normalize ? v[e] / nrm : v[e];
+        }
     }
 }
 
@@ -1117,8 +1156,8 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
     static const bool ln_off = getenv("MI_GEMM_LN") && atoi(getenv("MI_GEMM_LN")) == 0;
     const bool fused_ln = !ln_off && H == LN_N && I % 64 == 0;
     MI_HIP(hipEventRecord(e->ev0, st));
-    if (H <= 384) embed_ln_kernel<6><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
-    else embed_ln_kernel<16><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
+    if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
+    else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     for (const LayerW& lw : e->layers) {
         launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H);
         attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, scale_log2e);
@@ -1138,8 +1177,8 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
             else add_ln_kernel<2><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
         }
     }
-    if (H <= 512) pool_kernel<1><<<(unsigned)B, 256, 0, st>>>(h, mask, L, H, c.normalize, out);
-    else pool_kernel<2><<<(unsigned)B, 256, 0, st>>>(h, mask, L, H, c.normalize, out);
+    if (H <= 512) pool_kernel<1><<<(unsigned)B, 64 * POOL_WAVES, 0, st>>>(h, mask, L, H, c.normalize, out);
+    else pool_kernel<2><<<(unsigned)B, 64 * POOL_WAVES, 0, st>>>(h, mask, L, H, c.normalize, out);
     MI_HIP(hipEventRecord(e->ev1, st));
     MI_HIP(hipGetLastError());
     e->timed = true;
