@@ -94,6 +94,16 @@ __device__ __forceinline__ void wait_units(int units)
 // at the bottom of the iteration.  The plan picks.
 // M16: score with v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same LDS image, same bytes read,
 // same MFMA cycles per k; the guide measured a higher sustained clock on that shape).
+#ifdef MF_TRACE
+// Debug build only (tools/trace_scan.sh): cycle stamps of 64 consecutive units of four workgroups.
+#define MF_TRACE_U0 3000
+__device__ uint32_t mf_trace_buf[4][8][64][8];
+__device__ __forceinline__ int mf_trace_slot(int b) { return b == 3 ? 0 : b == 300 ? 1 : b == 700 ? 2 : b == 1200 ? 3 : -1; }
+#define MF_TRACE_LDS 16384
+#else
+#define MF_TRACE_LDS 0
+#endif
+
 template <int NKB, int KP, bool L2, int PD, bool M16>
 __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     const uint16_t* __restrict__ rows, const float* __restrict__ xx, int64_t n, int pitch_bytes,
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     constexpr int MF_GT_OFF = MF_XX_OFF + MF_XXB * MF_TILE_R * 4;   // shared-threshold words: [MF_XXB][waves][64] u32
     constexpr int MF_LDS_BYTES = MF_GT_OFF + MF_XXB * 8 * 256;
     static_assert(PD == 2 || PD == 3, "ring of 4 buffers: PD + 1 (+ 1 when the issue sits before the barrier)");
-    __shared__ __attribute__((aligned(1024))) char lds[MF_LDS_BYTES];
+    __shared__ __attribute__((aligned(1024))) char lds[MF_LDS_BYTES + MF_TRACE_LDS];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -229,14 +239,8 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                         acc16[rb][cb][2] = -0.5f * v.z; acc16[rb][cb][3] = -0.5f * v.w;
                     }
                 }
-            } else {
-#pragma unroll
-                for (int rb = 0; rb < 8; ++rb)
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc16[rb][cb][i] = 0.0f;
             }
+            // IP: nothing to do, the tile's first MFMA per accumulator takes a zero C operand
         } else if constexpr (L2) {
             const float* xl = reinterpret_cast<const float*>(lds + MF_XX_OFF + (tile & (MF_XXB - 1)) * (MF_TILE_R * 4));
 #pragma unroll
@@ -247,11 +251,6 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                     acc[m][4 * g + 0] = -0.5f * v.x; acc[m][4 * g + 1] = -0.5f * v.y;
                     acc[m][4 * g + 2] = -0.5f * v.z; acc[m][4 * g + 3] = -0.5f * v.w;
                 }
-        } else {
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[m][i] = 0.0f;
         }
     };
 
@@ -295,8 +294,12 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                              : "+v"(a[t & 1][0]), "+v"(a[t & 1][1]), "+v"(a[t & 1][2]), "+v"(a[t & 1][3]));
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t & 1][m], bq[KB * 8 + s], acc[m], 0, 0, 0);
+            for (int m = 0; m < 4; ++m) {
+                if (!L2 && KB == 0 && s == 0)          // first touch in the tile: C = 0 (no zeroing pass)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t & 1][m], bq[KB * 8 + s], f32x16{}, 0, 0, 0);
+                else
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t & 1][m], bq[KB * 8 + s], acc[m], 0, 0, 0);
+            }
         }
     };
 
@@ -332,9 +335,14 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-                    acc16[4 * (t & 1) + r][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        a[t & 1][r], bq16[KB * 4 + (t >> 1)][cb], acc16[4 * (t & 1) + r][cb], 0, 0, 0);
+                for (int cb = 0; cb < 2; ++cb) {
+                    if (!L2 && KB == 0 && t < 2)       // first touch in the tile: C = 0 (no zeroing pass)
+                        acc16[4 * (t & 1) + r][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            a[t & 1][r], bq16[KB * 4 + (t >> 1)][cb], f32x4{}, 0, 0, 0);
+                    else
+                        acc16[4 * (t & 1) + r][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            a[t & 1][r], bq16[KB * 4 + (t >> 1)][cb], acc16[4 * (t & 1) + r][cb], 0, 0, 0);
+                }
         }
     };
 
@@ -389,17 +397,28 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     // ---- filter: anything above the query's running threshold leaves the accumulators.
     // Rows are < 2^32 (plan); the row base changes per tile, so the per-element row numbers are
     // formed where they are used (hoisted out of the loop they would be spilled).
+    // the shared thresholds of this tile arrived with its first unit; read ahead of the last chain
+    auto refresh_thr = [&](int tile) __attribute__((always_inline)) {
+        const char* gslot = lds + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256;
+        if constexpr (M16) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const uint32_t gw = *reinterpret_cast<const uint32_t*>(gslot + (16 * cb + l15) * 4);
+                if (gw != 0) thr2[cb] = __builtin_fmaxf(thr2[cb], mi_unord_f32(gw));
+            }
+        } else {
+            const uint32_t gw = *reinterpret_cast<const uint32_t*>(gslot + col * 4);
+            if (gw != 0) thr = __builtin_fmaxf(thr, mi_unord_f32(gw));
+        }
+    };
     auto filter_tile = [&](int tile) __attribute__((always_inline)) {
         const uint32_t rend = (uint32_t)row_end;
-        const char* gslot = lds + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256;
         if constexpr (M16) {
             // the lane holds rows 16 rb + 4 g4 + reg of queries 16 cb + l15; a query's results sit in
             // the four lanes l15 + 16 g
             const uint32_t rowbase = (uint32_t)(row_begin + (int64_t)tile * MF_TILE_R) + 4u * (uint32_t)g4;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
-                const uint32_t gw = *reinterpret_cast<const uint32_t*>(gslot + (16 * cb + l15) * 4);
-                if (gw != 0) thr2[cb] = __builtin_fmaxf(thr2[cb], mi_unord_f32(gw));
                 uint64_t* const list16 = lists + ((int64_t)slice * nq_pad + qbase + 16 * cb + l15) * CAP;
 #pragma unroll
                 for (int rp = 0; rp < 4; ++rp) {                  // 32 rows at a time, as the list capacity assumes
@@ -438,10 +457,6 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
             }
         } else {
             const uint32_t rowbase = (uint32_t)(row_begin + (int64_t)tile * MF_TILE_R) + 4u * (uint32_t)h;
-            {
-                const uint32_t gw = *reinterpret_cast<const uint32_t*>(gslot + col * 4);
-                if (gw != 0) thr = __builtin_fmaxf(thr, mi_unord_f32(gw));
-            }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const f32x16 c = acc[m];
@@ -491,6 +506,18 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     // (A half-unit stagger of waves 4..7 against their SIMD partners was built and dropped in round
     // 1: the second code path costs ~15 registers and hipcc spilled query fragments into the loop.)
     int u = 0;
+#ifdef MF_TRACE
+    const int tslot = mf_trace_slot(blockIdx.x);
+    uint32_t* const tr = reinterpret_cast<uint32_t*>(lds + MF_LDS_BYTES) + wave * 512;
+    auto stamp = [&](int k) __attribute__((always_inline)) {
+        if (tslot >= 0 && u >= MF_TRACE_U0 && u < MF_TRACE_U0 + 64) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_s_memtime();
+            if (lane == 0) tr[(u - MF_TRACE_U0) * 8 + k] = t;
+        }
+    };
+#else
+    auto stamp = [&](int) __attribute__((always_inline)) {};
+#endif
     for (int tile = 0; tile < ntiles; ++tile) {
         static_for<NKB>([&](auto KBc) __attribute__((always_inline)) {
             constexpr int kb = decltype(KBc)::value;
@@ -498,16 +525,37 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
             // last barrier (unit u - 1's).  PD = 2 (MFMA-bound): unit u + 2 is issued at the BOTTOM
             // of the iteration instead, behind the unit's MFMAs; its buffer held unit u - 2.
             const bool more = u + PD < nunits;
+            stamp(0);
             if constexpr (PD == 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
+            if constexpr (kb == NKB - 1) { if (active) refresh_thr(tile); }
             if (active) { if constexpr (M16) chain16(u & (MF_NST - 1), IC<kb>{}); else chain(u & (MF_NST - 1), IC<kb>{}, IC<0>{}, IC<8>{}); }
+            stamp(1);
             if constexpr (PD != 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
+            // The filter needs nothing from the other waves, so it runs BEFORE the barrier: the waves
+            // that won the matrix pipe (the older four, in practice) filter while their SIMD
+            // partners still have MFMAs in flight, instead of everyone filtering after the barrier
+            // with the pipe idle.
+            stamp(6);
+            if constexpr (kb == NKB - 1) { if (active) filter_tile(tile); }
+            stamp(2);
+#ifdef MF_TRACE
+            { const int rem = nunits - 2 - u; wait_units<PPW>(rem < 0 ? 0 : (rem < MF_PD - 1 ? rem : MF_PD - 1)); stamp(3); __builtin_amdgcn_s_barrier(); stamp(4); }
+#else
             end_of_unit(u);
+#endif
             ++u;
         });
-        if (!active) continue;
-        filter_tile(tile);
-        if (tile + 1 < ntiles) init_acc(tile + 1);
+        if constexpr (L2) { if (active && tile + 1 < ntiles) init_acc(tile + 1); }
+#ifdef MF_TRACE
+        --u; stamp(5); ++u;
+#endif
     }
+#ifdef MF_TRACE
+    if (tslot >= 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        for (int i = lane; i < 512; i += 64) (&mf_trace_buf[tslot][wave][0][0])[i] = tr[i];
+    }
+#endif
 
     if constexpr (M16) {
         if (g4 == 0) {
@@ -887,3 +935,10 @@ int mi_launch_mfma_certify(hipStream_t st, const mi_mfma_plan* p, int metric, in
     MI_HIP(hipGetLastError());
     return MI_OK;
 }
+
+#ifdef MF_TRACE
+extern "C" int mi_debug_read_trace(void* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mf_trace_buf), sizeof(mf_trace_buf));
+}
+#endif
