@@ -86,6 +86,21 @@ __device__ __forceinline__ void wait_units(int units)
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
+// 16-byte LDS-DMA with the base address in SGPRs and a 32-bit per-lane offset (the builtin always
+// takes a 64-bit VGPR address: two 64-bit vector adds per piece, and the hoisted pairs spilled).
+__device__ __forceinline__ void dma16_saddr(const char* ubase, unsigned voff, unsigned lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(ubase), "s"(lds_addr) : "memory", "m0");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm()
+{
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
 // ---------------------------------------------------------------- phase 1
 // PD = LDS-DMA prefetch distance in units, ring of 4 buffers.  Measured on one device at
 // 100M x 384: a deep prefetch (PD = 3, issued at the top of an iteration) is 5-15 % faster where
@@ -96,7 +111,9 @@ __device__ __forceinline__ void wait_units(int units)
 // same MFMA cycles per k; the guide measured a higher sustained clock on that shape).
 #ifdef MF_TRACE
 // Debug build only (tools/trace_scan.sh): cycle stamps of 64 consecutive units of four workgroups.
+#ifndef MF_TRACE_U0
 #define MF_TRACE_U0 3000
+#endif
 __device__ uint32_t mf_trace_buf[4][8][64][8];
 __device__ __forceinline__ int mf_trace_slot(int b) { return b == 3 ? 0 : b == 300 ? 1 : b == 700 ? 2 : b == 1200 ? 3 : -1; }
 #define MF_TRACE_LDS 16384
@@ -123,6 +140,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     static_assert(PD == 2 || PD == 3, "ring of 4 buffers: PD + 1 (+ 1 when the issue sits before the barrier)");
     __shared__ __attribute__((aligned(1024))) char lds[MF_LDS_BYTES + MF_TRACE_LDS];
 
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
@@ -186,8 +204,10 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     // (4p = 16 (..) + 4 (i & 3), lr < 4), so one register pair and one xor constant per piece do.
     // Tiles may run past row_end / n by up to MF_TILE_R - 1 rows: the index allocates that much
     // slack behind its rows (capi.hip), and the filter masks those rows.
-    const char* pb0 = reinterpret_cast<const char*>(rows) + (row_begin + 4 * wave * PPW + lr) * (int64_t)pitch_bytes;
-    const unsigned sw0 = (unsigned)(lt ^ lr) << 4;
+    // The address is formed as (wave-uniform 64-bit base) + (per-lane 32-bit offset) so the load takes
+    // its base from SGPRs: no 64-bit vector adds per piece.
+    const char* const ub0 = reinterpret_cast<const char*>(rows) + (row_begin + 4 * wave * PPW) * (int64_t)pitch_bytes;
+    const unsigned voff0 = (unsigned)lr * (unsigned)pitch_bytes + ((unsigned)(lt ^ lr) << 4);   // pitch is a multiple of 256
 
     // gthr[q]: the best threshold any workgroup has published for query q (orderable word, 0 =
     // none yet).  Any slice's K'-th best is a lower bound of the global K'-th best, so every
@@ -207,11 +227,11 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                         (lds_ptr_t)(lds + MF_XX_OFF + (tile & (MF_XXB - 1)) * (MF_TILE_R * 4) + half * 256), 4, 0, 0);
             }
         }
-        const int64_t off = (int64_t)tile * MF_TILE_R * pitch_bytes + kb * 256;      // wave-uniform
+        const char* const ub = ub0 + ((int64_t)tile * MF_TILE_R * pitch_bytes + kb * 256);      // wave-uniform
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(pb0 + (off + (int64_t)i * 4 * pitch_bytes) + (sw0 ^ ((i & 3) << 6))),
-                (lds_ptr_t)(lds + buf * MF_STAGE_BYTES + (wave * PPW + i) * 1024), 16, 0, 0);
+            dma16_saddr(ub + (int64_t)i * 4 * pitch_bytes, voff0 ^ ((unsigned)(i & 3) << 6),
+                        lds_base + buf * MF_STAGE_BYTES + (wave * PPW + i) * 1024);
     };
     auto issue_linear = [&](int u) __attribute__((always_inline)) {                      // u < nunits
         issue_unit(u / NKB, u % NKB, u & (MF_NST - 1));
@@ -257,15 +277,19 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     // A-fragment read address: row (32 m + col), chunk (2 s + h) ^ (row & 15)
     const int a_row_off = col * 256;
     const unsigned a_swz = (unsigned)(h ^ (lane & 15)) << 4;
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
     // ---- prologue: put MF_PD units in flight, retire unit 0
+    constexpr int MF_PRO = M16 ? 3 : MF_PD;
 #pragma unroll
-    for (int u0 = 0; u0 < MF_PD; ++u0)
+    for (int u0 = 0; u0 < MF_PRO; ++u0)
         if (u0 < nunits) issue_linear(u0);
     if (nunits > 0) {
-        const int younger = (nunits - 1 < MF_PD - 1) ? nunits - 1 : MF_PD - 1;
-        wait_units<PPW>(younger);
+        if constexpr (M16) {
+            wait_vm<0>();                                // once per workgroup: simply drain
+        } else {
+            const int younger = (nunits - 1 < MF_PD - 1) ? nunits - 1 : MF_PD - 1;
+            wait_units<PPW>(younger);
+        }
         __builtin_amdgcn_s_barrier();
         if (active) init_acc(0);
     }
@@ -306,7 +330,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     // 16x16x32: per 32-wide k-step s (4 per unit) eight A fragments, rows 16 rb + l15, chunk
     // (4 s + g4) ^ l15 = (g4 ^ l15) ^ 4 s; read and consumed four row blocks at a time, one
     // group ahead, 8 MFMAs (4 row blocks x 2 query blocks, 16 cycles each) per group.
-    auto chain16 = [&](int buf, auto KBc) __attribute__((always_inline)) {
+    auto chain16 = [&](int buf, auto KBc, auto&& mid) __attribute__((always_inline)) {
         constexpr int KB = decltype(KBc)::value;
         const unsigned cur = (lds_base + buf * MF_STAGE_BYTES + l15 * 256) | ((unsigned)(g4 ^ l15) << 4);
         bf16x8 a[2][4];
@@ -343,6 +367,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                         acc16[4 * (t & 1) + r][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             a[t & 1][r], bq16[KB * 4 + (t >> 1)][cb], acc16[4 * (t & 1) + r][cb], 0, 0, 0);
                 }
+            if (t == 3) mid();
         }
     };
 
@@ -416,6 +441,23 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
         if constexpr (M16) {
             // the lane holds rows 16 rb + 4 g4 + reg of queries 16 cb + l15; a query's results sit in
             // the four lanes l15 + 16 g
+            // common case first, as one wide max tree and ONE branch per tile (eight dependent
+            // max -> compare -> branch rounds cost ~90 cycles each)
+            {
+                float m[2];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    float m4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) m4[i] = __builtin_fmaxf(acc16[0][cb][i], acc16[1][cb][i]);
+#pragma unroll
+                    for (int rb = 2; rb < 8; ++rb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) m4[i] = __builtin_fmaxf(m4[i], acc16[rb][cb][i]);
+                    m[cb] = __builtin_fmaxf(__builtin_fmaxf(m4[0], m4[1]), __builtin_fmaxf(m4[2], m4[3]));
+                }
+                if (__builtin_amdgcn_ballot_w64((m[0] > thr2[0]) || (m[1] > thr2[1])) == 0) return;
+            }
             const uint32_t rowbase = (uint32_t)(row_begin + (int64_t)tile * MF_TILE_R) + 4u * (uint32_t)g4;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
@@ -518,37 +560,81 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
 #else
     auto stamp = [&](int) __attribute__((always_inline)) {};
 #endif
-    for (int tile = 0; tile < ntiles; ++tile) {
-        static_for<NKB>([&](auto KBc) __attribute__((always_inline)) {
-            constexpr int kb = decltype(KBc)::value;
-            // PD = 3 (HBM-bound): unit u + 3 is issued here, into the buffer everyone left at the
-            // last barrier (unit u - 1's).  PD = 2 (MFMA-bound): unit u + 2 is issued at the BOTTOM
-            // of the iteration instead, behind the unit's MFMAs; its buffer held unit u - 2.
-            const bool more = u + PD < nunits;
-            stamp(0);
-            if constexpr (PD == 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
-            if constexpr (kb == NKB - 1) { if (active) refresh_thr(tile); }
-            if (active) { if constexpr (M16) chain16(u & (MF_NST - 1), IC<kb>{}); else chain(u & (MF_NST - 1), IC<kb>{}, IC<0>{}, IC<8>{}); }
-            stamp(1);
-            if constexpr (PD != 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
-            // The filter needs nothing from the other waves, so it runs BEFORE the barrier: the waves
-            // that won the matrix pipe (the older four, in practice) filter while their SIMD
-            // partners still have MFMAs in flight, instead of everyone filtering after the barrier
-            // with the pipe idle.
-            stamp(6);
-            if constexpr (kb == NKB - 1) { if (active) filter_tile(tile); }
-            stamp(2);
-#ifdef MF_TRACE
-            { const int rem = nunits - 2 - u; wait_units<PPW>(rem < 0 ? 0 : (rem < MF_PD - 1 ? rem : MF_PD - 1)); stamp(3); __builtin_amdgcn_s_barrier(); stamp(4); }
-#else
-            end_of_unit(u);
-#endif
-            ++u;
-        });
-        if constexpr (L2) { if (active && tile + 1 < ntiles) init_acc(tile + 1); }
-#ifdef MF_TRACE
-        --u; stamp(5); ++u;
-#endif
+    if constexpr (M16) {
+        // MFMA-bound variant.  The barrier sits in the MIDDLE of a unit's chain and certifies the NEXT
+        // unit: past it, unit u + 1 has landed for everyone and everyone has left unit u - 1.  A unit
+        // boundary is then no synchronisation point: a wave runs from the last MFMA of unit u straight
+        // into the first reads of unit u + 1, the two waves of a SIMD drift apart (the older one
+        // wins the pipe) and each one's filter / DMA issue / first-read latency hides behind the
+        // other's MFMAs.  Unit u + 3 is issued at the bottom of unit u into the buffer of unit u - 1
+        // (ring of 4); at the barrier of unit u the only younger DMA in flight is unit u + 2's.
+        for (int tile = 0; tile < ntiles; ++tile) {
+            static_for<NKB>([&](auto KBc) __attribute__((always_inline)) {
+                constexpr int kb = decltype(KBc)::value;
+                constexpr bool g2 = ((kb + 2) % NKB) == 0;          // unit u + 2 carries the threshold (and xx) loads
+                stamp(0);
+                if constexpr (kb == NKB - 1) { if (active) refresh_thr(tile); }
+                auto mid = [&]() __attribute__((always_inline)) {
+                    stamp(1);
+                    if (u + 2 < nunits) {
+                        if (L2 && wave == 0) wait_vm<PPW + (g2 ? 3 : 0)>(); else wait_vm<PPW + (g2 ? 1 : 0)>();
+                    } else {
+                        wait_vm<0>();
+                    }
+                    stamp(3);
+                    __builtin_amdgcn_s_barrier();
+                    // (Alternating the SIMD's two waves with s_setprio after this barrier does make them
+                    // take turns, but a wave alone on the pipe is LDS-latency-bound with one group of
+                    // read-ahead: measured 1 % slower.)
+                    stamp(4);
+                };
+                if (active) chain16(u & (MF_NST - 1), IC<kb>{}, mid); else mid();
+                stamp(5);
+                if (u + 3 < nunits) issue_unit(tile + (kb + 3) / NKB, (kb + 3) % NKB, (u + 3) & (MF_NST - 1));
+                stamp(6);
+                if constexpr (kb == NKB - 1) {
+                    if (active) {
+                        filter_tile(tile);
+                        if constexpr (L2) { if (tile + 1 < ntiles) init_acc(tile + 1); }
+                    }
+                }
+                stamp(2);
+                ++u;
+            });
+        }
+    } else {
+        for (int tile = 0; tile < ntiles; ++tile) {
+            static_for<NKB>([&](auto KBc) __attribute__((always_inline)) {
+                constexpr int kb = decltype(KBc)::value;
+                // PD = 3 (HBM-bound): unit u + 3 is issued here, into the buffer everyone left at the
+                // last barrier (unit u - 1's).  PD = 2 (MFMA-bound): unit u + 2 is issued at the BOTTOM
+                // of the iteration instead, behind the unit's MFMAs; its buffer held unit u - 2.
+                const bool more = u + PD < nunits;
+                stamp(0);
+                if constexpr (PD == 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
+                if constexpr (kb == NKB - 1) { if (active) refresh_thr(tile); }
+                if (active) { if constexpr (M16) chain16(u & (MF_NST - 1), IC<kb>{}, [] {}); else chain(u & (MF_NST - 1), IC<kb>{}, IC<0>{}, IC<8>{}); }
+                stamp(1);
+                if constexpr (PD != 3) { if (more) issue_unit(tile + (kb + PD) / NKB, (kb + PD) % NKB, (u + PD) & (MF_NST - 1)); }
+                // The filter needs nothing from the other waves, so it runs BEFORE the barrier: the waves
+                // that won the matrix pipe (the older four, in practice) filter while their SIMD
+                // partners still have MFMAs in flight, instead of everyone filtering after the barrier
+                // with the pipe idle.
+                stamp(6);
+                if constexpr (kb == NKB - 1) { if (active) filter_tile(tile); }
+                stamp(2);
+    #ifdef MF_TRACE
+                { const int rem = nunits - 2 - u; wait_units<PPW>(rem < 0 ? 0 : (rem < MF_PD - 1 ? rem : MF_PD - 1)); stamp(3); __builtin_amdgcn_s_barrier(); stamp(4); }
+    #else
+                end_of_unit(u);
+    #endif
+                ++u;
+            });
+            if constexpr (L2) { if (active && tile + 1 < ntiles) init_acc(tile + 1); }
+    #ifdef MF_TRACE
+            --u; stamp(5); ++u;
+    #endif
+        }
     }
 #ifdef MF_TRACE
     if (tslot >= 0) {
