@@ -279,7 +279,12 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     const unsigned a_swz = (unsigned)(h ^ (lane & 15)) << 4;
 
     // ---- prologue: put MF_PD units in flight, retire unit 0
-    constexpr int MF_PRO = M16 ? 3 : MF_PD;
+    // M16 variant: DMA lead in tenths of a unit.  25 = unit u + 3 issued at the bottom of unit u;
+    // 10 = unit u + 2 issued right behind the barrier of unit u.  Measured on one device (20M and
+    // 100M rows, 10k queries): 25 is 2-3 % faster at d = 384, 10 is 2 % faster at d = 768 and moves
+    // half the bytes over the fabric (the workgroups of a slice stay closer in L2); 15 and 20 lose.
+    constexpr int MF_LEAD = (NKB >= 6) ? 10 : 25;
+    constexpr int MF_PRO = M16 ? (MF_LEAD >= 20 ? 3 : 2) : MF_PD;
 #pragma unroll
     for (int u0 = 0; u0 < MF_PRO; ++u0)
         if (u0 < nunits) issue_linear(u0);
@@ -576,7 +581,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                 if constexpr (kb == NKB - 1) { if (active) refresh_thr(tile); }
                 auto mid = [&]() __attribute__((always_inline)) {
                     stamp(1);
-                    if (u + 2 < nunits) {
+                    if (MF_LEAD != 10 && u + 2 < nunits) {
                         if (L2 && wave == 0) wait_vm<PPW + (g2 ? 3 : 0)>(); else wait_vm<PPW + (g2 ? 1 : 0)>();
                     } else {
                         wait_vm<0>();
@@ -586,11 +591,12 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                     // (Alternating the SIMD's two waves with s_setprio after this barrier does make them
                     // take turns, but a wave alone on the pipe is LDS-latency-bound with one group of
                     // read-ahead: measured 1 % slower.)
+                    if constexpr (MF_LEAD == 10) { if (u + 2 < nunits) issue_unit(tile + (kb + 2) / NKB, (kb + 2) % NKB, (u + 2) & (MF_NST - 1)); }
                     stamp(4);
                 };
                 if (active) chain16(u & (MF_NST - 1), IC<kb>{}, mid); else mid();
                 stamp(5);
-                if (u + 3 < nunits) issue_unit(tile + (kb + 3) / NKB, (kb + 3) % NKB, (u + 3) & (MF_NST - 1));
+                if constexpr (MF_LEAD == 25) { if (u + 3 < nunits) issue_unit(tile + (kb + 3) / NKB, (kb + 3) % NKB, (u + 3) & (MF_NST - 1)); }
                 stamp(6);
                 if constexpr (kb == NKB - 1) {
                     if (active) {
