@@ -234,7 +234,7 @@ def main() -> int:
         ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(nloc, d, args.dtype, Q),
-                    "traffic_unit": "GB per launch (FETCH_SIZE PMC pass, profiles/r01_scan_pmc_v4.md)",
+                    "traffic_unit": "GB per launch (FETCH_SIZE PMC pass, profiles/r01_scan_pmc_v5.md)",
                     "kernel": "mfma_scan_kernel", "avg_launch_ms": round(avg_ms, 3),
                     "algorithmic_hbm_GBs": round(bytes_per_launch / (avg_ms * 1e-3) / 1e9, 1)}
     else:

@@ -500,8 +500,10 @@ static int search_dev_locked(mi_index* x, int64_t nq64, const float* q_dev, int 
     MI_TRY(x->lists.ensure(plan.list_bytes));
     MI_TRY(x->cnts.ensure(plan.cnt_bytes));
     MI_TRY(x->thrs.ensure(plan.thr_bytes));
-    MI_TRY(x->gthr.ensure((size_t)plan.nq_pad * sizeof(uint32_t)));
-    MI_HIP(hipMemsetAsync(x->gthr.p, 0, (size_t)plan.nq_pad * sizeof(uint32_t), st));
+    // shared thresholds [nq_pad], then the scan's per-slice progress words [nslices][64]
+    const size_t gthr_bytes = ((size_t)plan.nq_pad + (size_t)plan.nslices * 64) * sizeof(uint32_t);
+    MI_TRY(x->gthr.ensure(gthr_bytes));
+    MI_HIP(hipMemsetAsync(x->gthr.p, 0, gthr_bytes, st));
     // fail: [0] = count, [64 ..) = list of failed queries, then the per-query overflow flags
     MI_TRY(x->fail.ensure((size_t)(2 * (size_t)nq + 64) * sizeof(int32_t)));
     int32_t* fail_count = x->fail.as<int32_t>();

@@ -67,7 +67,7 @@ void mi_mfma_eps(int d_pad_scan, bool rounded_shadow, float* eps_acc, float* eps
 // rows: bf16 [n][d_pad]; xx: canonical squared norms (L2 only).
 int  mi_launch_mfma_scan(hipStream_t st, const mi_mfma_plan* p, int metric, const uint16_t* rows,
                          const float* xx, int64_t n, int d_pad, const uint16_t* q_bf16, int64_t nq,
-                         uint64_t* lists, int32_t* cnts, float* thrs, uint32_t* gthr /* [nq_pad], zeroed */);
+                         uint64_t* lists, int32_t* cnts, float* thrs, uint32_t* gthr /* [nq_pad + 64 nslices], zeroed */);
 // Phase 2: per (query, slice group): prefilter by MFMA score, canonical re-score from the
 // canonical rows (canon_dtype, pitch d_pad), exact top-k at out[q * out_stride + g * k + j].
 // over_flags[q] = 1 where a group had more near-ties than it can sort.

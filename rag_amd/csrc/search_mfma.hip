@@ -94,6 +94,26 @@ __device__ __forceinline__ void dma16_saddr(const char* ubase, unsigned voff, un
                  :: "v"(voff), "s"(ubase), "s"(lds_addr) : "memory", "m0");
 }
 
+// 4-byte LDS-DMA past this CU's L1 (sc1), SGPR base + 32-bit lane offset
+__device__ __forceinline__ void dma4_saddr_sc1(const void* ubase, unsigned voff, unsigned lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 sc1"
+                 :: "v"(voff), "s"(ubase), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void dma4_saddr(const void* ubase, unsigned voff, unsigned lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+                 :: "v"(voff), "s"(ubase), "s"(lds_addr) : "memory", "m0");
+}
+// lane * 4, formed where it is used: as a loop invariant hipcc hoists it, runs out of registers,
+// and reloads it from scratch in the loop (a vmem load + vmcnt(0): the prefetch drains)
+__device__ __forceinline__ unsigned lane_x4()
+{
+    unsigned l4;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 2, %0" : "=v"(l4));
+    return l4;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm()
 {
@@ -136,7 +156,8 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     constexpr int MF_NST = 4;                          // ring depth (units)
     constexpr int MF_XX_OFF = MF_NST * MF_STAGE_BYTES; // per-tile xx: [MF_XXB][128] f32
     constexpr int MF_GT_OFF = MF_XX_OFF + MF_XXB * MF_TILE_R * 4;   // shared-threshold words: [MF_XXB][waves][64] u32
-    constexpr int MF_LDS_BYTES = MF_GT_OFF + MF_XXB * 8 * 256;
+    constexpr int MF_PG_OFF = MF_GT_OFF + MF_XXB * 8 * 256;        // progress words of the slice's workgroups: [MF_XXB][64] u32
+    constexpr int MF_LDS_BYTES = MF_PG_OFF + MF_XXB * 256;
     static_assert(PD == 2 || PD == 3, "ring of 4 buffers: PD + 1 (+ 1 when the issue sits before the barrier)");
     __shared__ __attribute__((aligned(1024))) char lds[MF_LDS_BYTES + MF_TRACE_LDS];
 
@@ -207,27 +228,49 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     // The address is formed as (wave-uniform 64-bit base) + (per-lane 32-bit offset) so the load takes
     // its base from SGPRs: no 64-bit vector adds per piece.
     const char* const ub0 = reinterpret_cast<const char*>(rows) + (row_begin + 4 * wave * PPW) * (int64_t)pitch_bytes;
-    const unsigned voff0 = (unsigned)lr * (unsigned)pitch_bytes + ((unsigned)(lt ^ lr) << 4);   // pitch is a multiple of 256
+    // Kept in a register where there is one (2 % faster than forming it per unit); the K' = 128
+    // variants have none to spare (it would be spilled and reloaded with a vmcnt(0) per unit).
+    constexpr bool VOFF_INLINE = (KP >= 128) && M16;
+    const unsigned voff_reg = (unsigned)lr * (unsigned)pitch_bytes + ((unsigned)(lt ^ lr) << 4);   // pitch is a multiple of 256
 
     // gthr[q]: the best threshold any workgroup has published for query q (orderable word, 0 =
     // none yet).  Any slice's K'-th best is a lower bound of the global K'-th best, so every
     // workgroup may filter with it; a stale value is only a weaker, still valid, threshold.  It
     // arrives by LDS-DMA (sc1: past this CU's L1) with the tile's first unit.
-    const uint32_t* gsrc = gthr + (qglob - col) + (lane & 31);
+    const uint32_t* const gsrc_u = gthr + qbase;         // wave-uniform; lanes 32..63 re-read words 0..31
+    // prog[w]: tile reached by workgroup (slice, query tile w), + 1; 0 = not started, ~0 = done.
+    // The workgroups that stream one slice share one XCD's L2; nothing else keeps them together,
+    // and with a prefetch that never stalls they drift until most of their reads miss L2.  Every
+    // fourth tile a workgroup publishes its position and, if it leads a workgroup of its cohort by
+    // more than MF_MAX_LEAD tiles, naps until that one has caught up (bounded; the slowest never waits).
+    uint32_t* const prog = gthr + nq_pad + (int64_t)slice * 64;
+    // Measured at 100M x 384 x 10k on one device, lead limit 4 / 8 / 12 / 24 / none: 528 / 530 / 532 /
+    // 545 / 547 ms, fabric reads 194 / 200 / 257 / 489 / 1267 GB, clock under load 2.0 vs 1.93 GHz.
+    constexpr uint32_t MF_MAX_LEAD = 8, MF_COHORT = 512;
     // unit u = (tile, kb) lives in ring buffer u & (MF_NST - 1); its tile's xx in xx buffer tile & 3
     auto issue_unit = [&](int tile, int kb, int buf) __attribute__((always_inline)) {
-        if (kb == 0)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)gsrc,
-                (lds_ptr_t)(lds + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256), 4, 0, 16);
+        if (kb == 0) {
+            const unsigned l4 = lane_x4();
+            dma4_saddr_sc1(gsrc_u, l4 & 124u, lds_base + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256);
+            if constexpr (M16) {
+                if (wave == 0) dma4_saddr_sc1(prog, l4, lds_base + MF_PG_OFF + (tile & (MF_XXB - 1)) * 256);
+            }
+        }
         if constexpr (L2) {
             if (kb == 0 && wave == 0) {
+                const unsigned l4 = lane_x4();
 #pragma unroll
                 for (int half = 0; half < 2; ++half)
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xx + row_begin + (int64_t)tile * MF_TILE_R + 64 * half + lane),
-                        (lds_ptr_t)(lds + MF_XX_OFF + (tile & (MF_XXB - 1)) * (MF_TILE_R * 4) + half * 256), 4, 0, 0);
+                    dma4_saddr(xx + row_begin + (int64_t)tile * MF_TILE_R + 64 * half, l4,
+                               lds_base + MF_XX_OFF + (tile & (MF_XXB - 1)) * (MF_TILE_R * 4) + half * 256);
             }
         }
         const char* const ub = ub0 + ((int64_t)tile * MF_TILE_R * pitch_bytes + kb * 256);      // wave-uniform
+        unsigned voff0 = voff_reg;
+        if constexpr (VOFF_INLINE) {
+            const unsigned l4v = lane_x4(), lrv = l4v >> 6, ltv = (l4v >> 2) & 15u;
+            voff0 = lrv * (unsigned)pitch_bytes + ((ltv ^ lrv) << 4);
+        }
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             dma16_saddr(ub + (int64_t)i * 4 * pitch_bytes, voff0 ^ ((unsigned)(i & 3) << 6),
@@ -578,11 +621,28 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                 constexpr int kb = decltype(KBc)::value;
                 constexpr bool g2 = ((kb + 2) % NKB) == 0;          // unit u + 2 carries the threshold (and xx) loads
                 stamp(0);
+                if constexpr (kb == 0) {
+                    if (wave == 0 && (tile & 3) == 0 && nqt <= 64) {
+                        const uint32_t mine = (uint32_t)tile + 1u;
+                        const unsigned l4 = lane_x4();
+                        if (l4 == 0) __hip_atomic_store(prog + qt, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        uint32_t v = *reinterpret_cast<const uint32_t*>(lds + MF_PG_OFF + (tile & (MF_XXB - 1)) * 256 + l4);
+                        auto behind = [&](uint32_t w) { return w != 0u && w < mine && mine - w > MF_MAX_LEAD && mine - w <= MF_COHORT; };
+                        if (__builtin_amdgcn_ballot_w64(behind(v)) != 0) {
+                            for (int spin = 0; spin < 32; ++spin) {
+                                __builtin_amdgcn_s_sleep(32);
+                                v = __hip_atomic_load(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(prog) + (size_t)l4),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (__builtin_amdgcn_ballot_w64(behind(v)) == 0) break;
+                            }
+                        }
+                    }
+                }
                 if constexpr (kb == NKB - 1) { if (active) refresh_thr(tile); }
                 auto mid = [&]() __attribute__((always_inline)) {
                     stamp(1);
                     if (MF_LEAD != 10 && u + 2 < nunits) {
-                        if (L2 && wave == 0) wait_vm<PPW + (g2 ? 3 : 0)>(); else wait_vm<PPW + (g2 ? 1 : 0)>();
+                        if (wave == 0) wait_vm<PPW + (g2 ? (L2 ? 4 : 2) : 0)>(); else wait_vm<PPW + (g2 ? 1 : 0)>();
                     } else {
                         wait_vm<0>();
                     }
@@ -650,6 +710,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
 #endif
 
     if constexpr (M16) {
+        if (threadIdx.x == 0 && nqt <= 64) __hip_atomic_store(prog + qt, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (g4 == 0) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
