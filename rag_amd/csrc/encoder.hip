@@ -49,22 +49,38 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi)
     return __builtin_bit_cast(uint32_t, v);
 }
 
-// erf-GELU, x * 0.5 * (1 + erf(x / sqrt 2)), with erf from Abramowitz & Stegun 7.1.26
-// (|error| <= 1.5e-7, far below the bf16 rounding of the result): one v_rcp, one v_exp and a
-// degree-5 Horner chain instead of ocml's branchy erff.  (modeling_bert.py:334-337, activations.py GELUActivation)
-__device__ __forceinline__ float gelu_erf(float x)
+// erf-GELU, x * 0.5 * (1 + erf(x / sqrt 2))  (modeling_bert.py:334-337, activations.py GELUActivation), as
+//   gelu(x) = max(x, 0) - |x| / 2 * erfc(|x| / sqrt 2),   erfc(z) ~= 2^(-z q(z)),
+// q a degree-4 polynomial fitted (minimax, z in [0, 4.5], increasing beyond) to -log2(erfc(z)) / z:
+// |erfc error| <= 6.8e-7 evaluated in fp32, far below the bf16 rounding of the result.  One v_exp,
+// no reciprocal, no sign fix-up: 9 full-rate operations per value against 14 + v_rcp for
+// Abramowitz-Stegun 7.1.26, and the Horner chain runs two values per instruction (v_pk_fma_f32).
+// FFN1 spends as long in this function as in its MFMAs, so its cost is the kernel's.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x)
 {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    poly = __builtin_fmaf(poly, t, 1.421413741f);
-    poly = __builtin_fmaf(poly, t, -0.284496736f);
-    poly = __builtin_fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erf_abs = __builtin_fmaf(-poly, e, 1.0f);            // erf(|x| / sqrt 2)
-    const float erf_v = __builtin_copysignf(erf_abs, x);
-    return 0.5f * x * (1.0f + erf_v);
+    f32x2 z;
+    z.x = fabsf(x.x) * 0.70710678118654752440f;
+    z.y = fabsf(x.y) * 0.70710678118654752440f;
+    f32x2 q = __builtin_elementwise_fma(z, f32x2{0.0029441735549769255f, 0.0029441735549769255f},
+                                        f32x2{-0.0295900954803597f, -0.0295900954803597f});
+    q = __builtin_elementwise_fma(q, z, f32x2{0.14866568630789534f, 0.14866568630789534f});
+    q = __builtin_elementwise_fma(q, z, f32x2{0.9185093434591132f, 0.9185093434591132f});
+    q = __builtin_elementwise_fma(q, z, f32x2{1.6278890079463915f, 1.6278890079463915f});
+    const f32x2 p = q * z;
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(-p.x);
+    e.y = __builtin_amdgcn_exp2f(-p.y);
+    const f32x2 t = z * -0.70710678118654752440f;                    // -|x| / 2
+    f32x2 r;                                                          // max(x, 0) in one instruction
+    r.x = __builtin_amdgcn_fmed3f(x.x, 0.0f, __builtin_inff());
+    r.y = __builtin_amdgcn_fmed3f(x.y, 0.0f, __builtin_inff());
+    return __builtin_elementwise_fma(t, e, r);
+}
+__device__ __forceinline__ void gelu_erf4(float& v0, float& v1, float& v2, float& v3)
+{
+    const f32x2 a = gelu_erf2(f32x2{v0, v1}), b = gelu_erf2(f32x2{v2, v3});
+    v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
 }
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const uint16_t* __res
                 const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + nl);
                 float v0 = acc[ni][mi][4 * g + 0] + bv.x, v1 = acc[ni][mi][4 * g + 1] + bv.y;
                 float v2 = acc[ni][mi][4 * g + 2] + bv.z, v3 = acc[ni][mi][4 * g + 3] + bv.w;
-                if constexpr (EPI == EPI_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                if constexpr (EPI == EPI_GELU) gelu_erf4(v0, v1, v2, v3);
                 if constexpr (EPI == EPI_RESID) {
                     *reinterpret_cast<float4*>(lds + rl * GM_TS32 + nl * 4) = make_float4(v0, v1, v2, v3);
                 } else {
@@ -509,7 +525,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
                     for (int nb = 0; nb < 2; ++nb) {
                         const f32x4 v = acc[mb][nb];
                         float v0 = v[0] + bv[nb].x, v1 = v[1] + bv[nb].y, v2 = v[2] + bv[nb].z, v3 = v[3] + bv[nb].w;
-                        if constexpr (EPI == EPI_GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                        if constexpr (EPI == EPI_GELU) gelu_erf4(v0, v1, v2, v3);
                         *reinterpret_cast<uint2*>(park + (16 * mb + l15) * WS_TS16 + (wave * 32 + 16 * nb + 4 * g4) * 2) =
                             make_uint2(pack2(v0, v1), pack2(v2, v3));
                     }
