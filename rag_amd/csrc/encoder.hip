@@ -577,18 +577,19 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
 // the activation tile is staged once per 384 columns instead of once per 128 (96 flop per staged
 // byte instead of 64).  v_mfma_f32_16x16x32_bf16 with the W fragment as the A operand: a lane owns
 // row (lane & 15) of a block and four consecutive columns, so bias / gamma / beta are float4 and
-// the finished tile is parked in LDS and leaves as whole 768-B rows.  Stages of 64 k (A 16 KB +
-// W 48 KB), LDS-DMA, double-buffered, 128-B rows swizzled as in gemm_bf16_kernel.
+// the finished tile is parked in LDS and leaves as whole 768-B rows.  Stages of 32 k (A 8 KB +
+// W 24 KB) by LDS-DMA in a ring of four, requested three stages ahead.
 // `out` may alias `resid`: a workgroup reads and writes only its own rows.
 #define LN_N 384
-#define LN_STAGE (512 * 128)                 // 128 A rows + 384 W rows, 128 B each
+#define LN_STAGE (512 * 64)                  // 128 A rows + 384 W rows, 64 B (32 k) each
 #define LN_TS 784                            // parked bf16 row: 384 columns + 8 pad
 
 __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         const float* __restrict__ bias, const uint16_t* __restrict__ resid, const float* __restrict__ gamma,
         const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int K)
 {
-    __shared__ __attribute__((aligned(1024))) char lds[2 * LN_STAGE];
+    __shared__ __attribute__((aligned(1024))) char lds[4 * LN_STAGE];
+    static_assert(4 * LN_STAGE >= 4096 + 128 * LN_TS, "the epilogue parks the tile in the ring");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, g4 = lane >> 4;
@@ -596,24 +597,29 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
     // last rows first: the producer kernel wrote them last, so they are the part of A still in the Infinity Cache
     const int m0 = (int)(gridDim.x - 1 - blockIdx.x) * 128;
 
-    // LDS-DMA: 16 A pieces + 48 W pieces per stage (8 rows x 128 B each); wave w: A pieces 2w, 2w+1, W pieces 6w..6w+5
-    const int lr = lane >> 3, lt = lane & 7;
+    // LDS-DMA.  A stage is 32 k: 512 rows (128 A + 384 W) x 64 B = 32 KB, ring of four.  (The first form
+    // had two 64-KB stages: the next stage could only be requested one stage ahead, and a stage took
+    // 2.6 us against 0.75 us of MFMA -- the L2 -> LDS latency, not the arithmetic, set the pace.)
+    // A piece is one DMA instruction: 16 rows x 64 B, lane l -> row l / 4, 16-B slot l % 4.
+    // Slot = chunk ^ swz(row), swz(r) = (0 - (r >> 2)) & 3: with that the four 16-lane groups a
+    // ds_read_b128 is served in (rows {0-3, 12-15} of one k-chunk and rows 4-11 of the next) each
+    // touch all 64 banks once.  Wave w issues pieces 4w..4w+3 (waves 0, 1: the A rows).
+    const int nkt = K / 32;                                        // even (K is a multiple of 64)
     const int64_t rowbytes = (int64_t)K * 2;
-    const char* src[8];
+    const char* src[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int p = (i < 2) ? 2 * wave + i : 16 + 6 * wave + (i - 2);          // piece = 8 rows of the stage image
-        const int r = 8 * p + lr;                                                // stage row: 0..127 A, 128..511 W
-        const int sw = (lt ^ ((r >> 1) & 7)) << 4;
-        if (i < 2) { int ra = m0 + r; if (ra > M - 1) ra = M - 1; src[i] = reinterpret_cast<const char*>(A) + ra * rowbytes + sw; }
-        else src[i] = reinterpret_cast<const char*>(W) + (int64_t)(r - 128) * rowbytes + sw;
+    for (int i = 0; i < 4; ++i) {
+        const int r = 16 * (4 * wave + i) + (lane >> 2);                          // stage row: 0..127 A, 128..511 W
+        const int ch = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+        if (wave < 2) { int ra = m0 + r; if (ra > M - 1) ra = M - 1; src[i] = reinterpret_cast<const char*>(A) + ra * rowbytes + ch * 16; }
+        else src[i] = reinterpret_cast<const char*>(W) + (int64_t)(r - 128) * 64 + ch * 16;          // W is packed [K / 32][384][32]
     }
-    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+    const int kstride = (wave < 2) ? 64 : LN_N * 64;               // A: 32 k further along the row; W: the next packed block
+    auto issue = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int p = (i < 2) ? 2 * wave + i : 16 + 6 * wave + (i - 2);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[i] + kt * 128), (lds_ptr_t)(lds + buf * LN_STAGE + p * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[i] + (int64_t)kt * kstride),
+                (lds_ptr_t)(lds + (kt & 3) * LN_STAGE + (4 * wave + i) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[2][12];                                  // [16-row block][16-column block]
@@ -624,64 +630,71 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[mb][nb][i] = 0.0f;
 
-    // fragment addresses: stage row r, 16-B chunk (4 s + g4) ^ ((r >> 1) & 7); r = base + l15 with base a
-    // multiple of 16, so (r >> 1) & 7 = l15 >> 1 and step s is one xor with a constant
+    // fragment addresses: stage row r = (multiple of 16) + l15, 16-B chunk g4 ^ swz(l15): constant per lane
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-    const unsigned fsw = (unsigned)(g4 ^ (l15 >> 1)) << 4;
-    const unsigned a_adr = lds_base + (unsigned)((32 * wm + l15) * 128) + fsw;            // + mb * 2048
-    const unsigned w_adr = lds_base + (unsigned)((128 + 192 * wn + l15) * 128) + fsw;     // + nb * 2048
+    const unsigned fsw = (unsigned)(g4 ^ ((0 - (l15 >> 2)) & 3)) << 4;
+    const unsigned a_adr = lds_base + (unsigned)((32 * wm + l15) * 64) + fsw;             // + mb * 1024
+    const unsigned w_adr = lds_base + (unsigned)((128 + 192 * wn + l15) * 64) + fsw;      // + nb * 1024
 
-    const int nkt = K / 64;
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
-        const unsigned ab = a_adr + buf * LN_STAGE, wb = w_adr + buf * LN_STAGE;
-        // 6 groups per stage: (k-step s, column group j) -> 4 W fragments, 8 MFMAs; the two A fragments
-        // of a k-step arrive with its group 0.  One group is read ahead of the one being multiplied.
-        bf16x8 af[2][2], wf[2][4];
-        auto rd_w = [&](bf16x8 (&f)[4], int s, int j) __attribute__((always_inline)) {
-            const unsigned ad = (wb + j * 8192) ^ ((unsigned)s << 6);
-            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\t"
-                         "ds_read_b128 %2, %4 offset:4096\n\tds_read_b128 %3, %4 offset:6144"
-                         : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]) : "v"(ad));
-        };
-        auto rd_a = [&](bf16x8 (&f)[2], int s) __attribute__((always_inline)) {
-            const unsigned ad = ab ^ ((unsigned)s << 6);
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:2048" : "=&v"(f[0]), "=&v"(f[1]) : "v"(ad));
-        };
-        rd_a(af[0], 0);
-        rd_w(wf[0], 0, 0);
+    // A stage is three groups of 4 W fragments x 2 A fragments = 8 MFMAs; fragments are read one group
+    // ahead, ACROSS stage boundaries.  The workgroup barrier sits behind the second group and
+    // certifies the NEXT stage (landed for everyone; everyone has left the previous one), so a
+    // stage boundary is no synchronisation point and stage kt + 3 is requested right behind it.
+    bf16x8 af[2][2], wf[2][4];
+    auto rd_w = [&](bf16x8 (&f)[4], int kt, int j) __attribute__((always_inline)) {
+        const unsigned ad = w_adr + (kt & 3) * LN_STAGE + j * 4096;
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                     "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                     : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]) : "v"(ad));
+    };
+    auto rd_a = [&](bf16x8 (&f)[2], int kt) __attribute__((always_inline)) {
+        const unsigned ad = a_adr + (kt & 3) * LN_STAGE;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(f[0]), "=&v"(f[1]) : "v"(ad));
+    };
+    auto mma = [&](bf16x8 (&w4)[4], bf16x8 (&a2)[2], int j) __attribute__((always_inline)) {
 #pragma unroll
-        for (int gq = 0; gq < 6; ++gq) {
-            const int s = gq / 3, j = gq % 3;
-            if (gq < 5) {
-                const int s1 = (gq + 1) / 3, j1 = (gq + 1) % 3;
-                if (j1 == 0) {
-                    rd_a(af[s1 & 1], s1);
-                    rd_w(wf[(gq + 1) & 1], s1, j1);
-                    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wf[gq & 1][0]), "+v"(wf[gq & 1][1]), "+v"(wf[gq & 1][2]), "+v"(wf[gq & 1][3]),
-                                 "+v"(af[s & 1][0]), "+v"(af[s & 1][1]));
-                } else {
-                    rd_w(wf[(gq + 1) & 1], s1, j1);
-                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[gq & 1][0]), "+v"(wf[gq & 1][1]), "+v"(wf[gq & 1][2]), "+v"(wf[gq & 1][3]),
-                                 "+v"(af[s & 1][0]), "+v"(af[s & 1][1]));
-                }
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[gq & 1][0]), "+v"(wf[gq & 1][1]), "+v"(wf[gq & 1][2]), "+v"(wf[gq & 1][3]),
-                             "+v"(af[s & 1][0]), "+v"(af[s & 1][1]));
-            }
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
-                    acc[mb][4 * j + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[gq & 1][q], af[s & 1][mb], acc[mb][4 * j + q], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            for (int mb = 0; mb < 2; ++mb)
+                acc[mb][4 * j + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w4[q], a2[mb], acc[mb][4 * j + q], 0, 0, 0);
+    };
+    // PAR = parity of the stage's first group (3 groups per stage: it alternates)
+    auto stage = [&](int kt, auto PARc) __attribute__((always_inline)) {
+        constexpr int P = decltype(PARc)::value;
+        bf16x8 (&a2)[2] = af[P];                                   // the stage's A fragments arrived with its group 0
+        rd_w(wf[P ^ 1], kt, 1);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[P][0]), "+v"(wf[P][1]), "+v"(wf[P][2]), "+v"(wf[P][3]), "+v"(a2[0]), "+v"(a2[1]));
+        mma(wf[P], a2, 0);
+        rd_w(wf[P], kt, 2);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[P ^ 1][0]), "+v"(wf[P ^ 1][1]), "+v"(wf[P ^ 1][2]), "+v"(wf[P ^ 1][3]));
+        mma(wf[P ^ 1], a2, 1);
+        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (kt + 3 < nkt) issue(kt + 3);
+        if (kt + 1 < nkt) {
+            rd_a(af[P ^ 1], kt + 1);
+            rd_w(wf[P ^ 1], kt + 1, 0);
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(wf[P][0]), "+v"(wf[P][1]), "+v"(wf[P][2]), "+v"(wf[P][3]));
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[P][0]), "+v"(wf[P][1]), "+v"(wf[P][2]), "+v"(wf[P][3]));
+        }
+        mma(wf[P], a2, 2);
+    };
+
+    issue(0);
+    if (nkt > 1) issue(1);
+    if (nkt > 2) issue(2);
+    if (nkt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    rd_a(af[0], 0);
+    rd_w(wf[0], 0, 0);
+    for (int kt = 0; kt < nkt; kt += 2) {
+        stage(kt, IC<0>{});
+        stage(kt + 1, IC<1>{});
     }
+    __syncthreads();                                               // the ring becomes the epilogue's scratch
 
     // ---- epilogue.  The lane holds, for rows m = m0 + 32 wm + 16 mb + l15, columns 192 wn + 16 nb + 4 g4 + (0..3).
     float* rs = reinterpret_cast<float*>(lds);                 // [2 passes][2 column halves][128 rows] row sums
@@ -969,6 +982,18 @@ __global__ __launch_bounds__(64 * POOL_WAVES) void pool_kernel(const uint16_t* _
 }
 
 // ---------------------------------------------------------------- weights: fp32 [n][k] -> bf16
+// fp32 [N][K] -> bf16 [K / 32][N][32]
+__global__ __launch_bounds__(256) void cvt_pack32_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int N, int K)
+{
+    const int64_t total = (int64_t)N * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(i & 31);
+        const int64_t t = i >> 5;
+        const int n = (int)(t % N), kb = (int)(t / N);
+        out[i] = f2bf(in[(int64_t)n * K + kb * 32 + kk]);
+    }
+}
+
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = mi_f32_to_bf16(in[i]);
@@ -977,6 +1002,7 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
 // ================================================================ host side
 struct LayerW {
     uint16_t *Wqkv, *Wo, *Wi, *Wd;                 // bf16 [out][in]
+    uint16_t *Wo_p = nullptr, *Wd_p = nullptr;     // the same, [in / 32][out][32]: a 32-k stage of gemm_ln_kernel is one contiguous block
     float *bqkv, *bo, *bi, *bd, *g1, *b1, *g2, *b2; // fp32
 };
 
@@ -1050,7 +1076,7 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
 #define ENC_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { mi_set_error("%s failed: %s", #call, hipGetErrorString(_e)); return fail(_e == hipErrorOutOfMemory ? MI_ERR_OOM : MI_ERR_HIP); } } while (0)
     ENC_HIP(hipMalloc((void**)&e->blob, (size_t)want * sizeof(float)));
     ENC_HIP(hipMemcpyAsync(e->blob, blob_host, (size_t)want * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    const int64_t per_layer_w = (int64_t)4 * H * H + 2 * (int64_t)I * H;
+    const int64_t per_layer_w = (int64_t)4 * H * H + 2 * (int64_t)I * H + ((int64_t)H * H + (int64_t)H * I);   // + packed Wo, Wd
     ENC_HIP(hipMalloc((void**)&e->wbf, (size_t)(per_layer_w * cfg->num_hidden_layers) * sizeof(uint16_t)));
     ENC_HIP(hipEventCreate(&e->ev0));
     ENC_HIP(hipEventCreate(&e->ev1));
@@ -1082,6 +1108,8 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
         lw.Wo = w; cvt(Wo, w, (int64_t)H * H); w += (int64_t)H * H;
         lw.Wi = w; cvt(Wi, w, (int64_t)I * H); w += (int64_t)I * H;
         lw.Wd = w; cvt(Wd, w, (int64_t)H * I); w += (int64_t)H * I;
+        lw.Wo_p = w; cvt_pack32_kernel<<<1024, 256, 0, e->stream>>>(Wo, w, H, H); w += (int64_t)H * H;
+        lw.Wd_p = w; cvt_pack32_kernel<<<1024, 256, 0, e->stream>>>(Wd, w, H, I); w += (int64_t)H * I;
         // fused qkv bias: bq|bk|bv are not contiguous in the blob -> a small packed copy
         ENC_HIP(hipMalloc((void**)&lw.bqkv, (size_t)3 * H * sizeof(float)));
         ENC_HIP(hipMemcpyAsync(lw.bqkv, bq, (size_t)H * 4, hipMemcpyDeviceToDevice, e->stream));
@@ -1178,7 +1206,7 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
         launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H);
         attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, scale_log2e);
         if (fused_ln) {
-            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(ctx, lw.Wo, lw.bo, h, lw.g1, lw.b1, c.layer_norm_eps, h, (int)T, H);
+            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(ctx, lw.Wo_p, lw.bo, h, lw.g1, lw.b1, c.layer_norm_eps, h, (int)T, H);
         } else {
             launch_gemm<EPI_RESID>(st, ctx, lw.Wo, lw.bo, h, tmp, (int)T, H, H);
             if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
@@ -1186,7 +1214,7 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
         }
         launch_gemm<EPI_GELU>(st, h, lw.Wi, lw.bi, nullptr, mid, (int)T, I, H);
         if (fused_ln) {
-            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(mid, lw.Wd, lw.bd, h, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I);
+            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(mid, lw.Wd_p, lw.bd, h, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I);
         } else {
             launch_gemm<EPI_RESID>(st, mid, lw.Wd, lw.bd, h, tmp, (int)T, H, I);
             if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
@@ -1215,7 +1243,8 @@ extern "C" int mi_encoder_encode_dev(mi_encoder* e, int64_t B, int L, const int3
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     int rc = MI_OK;
     // bounded workspace: at most 64K tokens per pass
-    const int64_t bmax = ((int64_t)65536 / L) > 0 ? (int64_t)65536 / L : 1;
+    static const int64_t pass_tokens = getenv("MI_ENC_PASS_TOKENS") ? atoll(getenv("MI_ENC_PASS_TOKENS")) : 65536;
+    const int64_t bmax = (pass_tokens / L) > 0 ? pass_tokens / L : 1;
     for (int64_t b0 = 0; b0 < B && rc == MI_OK; b0 += bmax) {
         const int64_t nb = (B - b0 < bmax) ? B - b0 : bmax;
         rc = encode_dev_locked(e, nb, L, ids_dev + b0 * L, mask_dev + b0 * L, out_emb_dev + b0 * e->cfg.hidden_size, st);
