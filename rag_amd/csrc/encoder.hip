@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const uint16_t* __res
 #define WS_LDS_BYTES (WS_PARK_OFF + 128 * WS_TS16)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int EPI>
+template <int EPI, bool BLK>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         const float* __restrict__ bias, const uint16_t* __restrict__ resid, uint16_t* __restrict__ C,
         int M, int N, int n_groups, int n_chunks)
@@ -531,12 +531,18 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
                     }
             }
             __syncthreads();
+            // one base per tile, then a constant 1-KB step per row group (rows r0 + 16 p of the 32-column block)
+            uint16_t* const blk_base = C + ((((m_base >> 7) * (N >> 5) + (n0 >> 5) + (ch >> 2)) * 128 + r0) * 32 + (ch & 3) * 8);
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int r = r0 + 16 * p;
                 const int64_t m = m_base + r;
-                if (m < M && col_ok)
-                    *reinterpret_cast<uint4*>(C + m * N + n0 + 8 * ch) = *reinterpret_cast<const uint4*>(park + r * WS_TS16 + ch * 16);
+                // BLK: rows past M lie in the padded last tile of the blocked buffer (never read back as results)
+                if ((BLK || m < M) && col_ok) {
+                    // BLK: C is [M / 128][N / 32][128][32] (what gemm_ln_kernel stages as whole 8-KB blocks)
+                    uint16_t* dst = BLK ? blk_base + p * 512 : C + m * N + n0 + 8 * ch;
+                    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(park + r * WS_TS16 + ch * 16);
+                }
             }
             // the next park write is three unit barriers away
         }
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
 
 __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         const float* __restrict__ bias, const uint16_t* __restrict__ resid, const float* __restrict__ gamma,
-        const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int K)
+        const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int K, int a_blocked)
 {
     __shared__ __attribute__((aligned(1024))) char lds[4 * LN_STAGE];
     static_assert(4 * LN_STAGE >= 4096 + 128 * LN_TS, "the epilogue parks the tile in the ring");
@@ -611,10 +617,17 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
     for (int i = 0; i < 4; ++i) {
         const int r = 16 * (4 * wave + i) + (lane >> 2);                          // stage row: 0..127 A, 128..511 W
         const int ch = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
-        if (wave < 2) { int ra = m0 + r; if (ra > M - 1) ra = M - 1; src[i] = reinterpret_cast<const char*>(A) + ra * rowbytes + ch * 16; }
+        if (wave < 2) {
+            if (a_blocked) {                                       // A is [M / 128][K / 32][128][32]: a stage is one 8-KB block
+                src[i] = reinterpret_cast<const char*>(A) + ((int64_t)(m0 >> 7) * (K >> 5) * 128 + r) * 64 + ch * 16;
+            } else {
+                int ra = m0 + r; if (ra > M - 1) ra = M - 1;
+                src[i] = reinterpret_cast<const char*>(A) + ra * rowbytes + ch * 16;
+            }
+        }
         else src[i] = reinterpret_cast<const char*>(W) + (int64_t)(r - 128) * 64 + ch * 16;          // W is packed [K / 32][384][32]
     }
-    const int kstride = (wave < 2) ? 64 : LN_N * 64;               // A: 32 k further along the row; W: the next packed block
+    const int kstride = (wave < 2) ? (a_blocked ? 128 * 64 : 64) : LN_N * 64;               // A: 32 k further along the row; W: the next packed block
     auto issue = [&](int kt) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1143,7 +1156,7 @@ extern "C" void mi_encoder_destroy(mi_encoder* e)
 // K = 384 projections on enough rows to fill the chip: the weight-stationary kernel
 template <int EPI>
 static bool launch_gemm_ws(hipStream_t st, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* resid,
-                           uint16_t* C, int M, int N, int K)
+                           uint16_t* C, int M, int N, int K, bool blocked_out)
 {
     static const bool off = getenv("MI_GEMM_WS") && atoi(getenv("MI_GEMM_WS")) == 0;
     // N = 384 (attention output) fills only 1.5 column groups: measured slower than the tile kernel
@@ -1154,18 +1167,21 @@ static bool launch_gemm_ws(hipStream_t st, const uint16_t* A, const uint16_t* W,
     int n_chunks = 32 / n_groups;
     if (n_chunks > m_tiles / 8) n_chunks = m_tiles / 8;
     if (n_chunks < 1) return false;
-    gemm_ws_kernel<EPI><<<256, 512, 0, st>>>(A, W, bias, resid, C, M, N, n_groups, n_chunks);
+    if (blocked_out && EPI != EPI_RESID) gemm_ws_kernel<EPI, true><<<256, 512, 0, st>>>(A, W, bias, resid, C, M, N, n_groups, n_chunks);
+    else gemm_ws_kernel<EPI, false><<<256, 512, 0, st>>>(A, W, bias, resid, C, M, N, n_groups, n_chunks);
     return true;
 }
 
 template <int EPI>
-static void launch_gemm(hipStream_t st, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* resid,
-                        uint16_t* C, int M, int N, int K)
+static bool launch_gemm(hipStream_t st, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* resid,
+                        uint16_t* C, int M, int N, int K, bool want_blocked = false)
 {
-    if (launch_gemm_ws<EPI>(st, A, W, bias, resid, C, M, N, K)) return;
+    // returns true iff C was written in the blocked layout (only the weight-stationary kernel can)
+    if (launch_gemm_ws<EPI>(st, A, W, bias, resid, C, M, N, K, want_blocked)) return want_blocked && EPI != EPI_RESID;
     const int n_tiles = N / GM_BN, m_tiles = (M + GM_BM - 1) / GM_BM;
     const unsigned grid = (unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles);
     gemm_bf16_kernel<EPI><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K, n_tiles, m_tiles);
+    return false;
 }
 
 // All device pointers; B*L tokens.  Caller holds the encoder mutex and has set the device.
@@ -1206,15 +1222,15 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
         launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H);
         attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, scale_log2e);
         if (fused_ln) {
-            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(ctx, lw.Wo_p, lw.bo, h, lw.g1, lw.b1, c.layer_norm_eps, h, (int)T, H);
+            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(ctx, lw.Wo_p, lw.bo, h, lw.g1, lw.b1, c.layer_norm_eps, h, (int)T, H, 0);
         } else {
             launch_gemm<EPI_RESID>(st, ctx, lw.Wo, lw.bo, h, tmp, (int)T, H, H);
             if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
             else add_ln_kernel<2><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
         }
-        launch_gemm<EPI_GELU>(st, h, lw.Wi, lw.bi, nullptr, mid, (int)T, I, H);
+        const bool mid_blocked = launch_gemm<EPI_GELU>(st, h, lw.Wi, lw.bi, nullptr, mid, (int)T, I, H, fused_ln);
         if (fused_ln) {
-            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(mid, lw.Wd_p, lw.bd, h, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I);
+            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(mid, lw.Wd_p, lw.bd, h, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I, mid_blocked ? 1 : 0);
         } else {
             launch_gemm<EPI_RESID>(st, mid, lw.Wd, lw.bd, h, tmp, (int)T, H, I);
             if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
