@@ -592,9 +592,9 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
 
 __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         const float* __restrict__ bias, const uint16_t* __restrict__ resid, const float* __restrict__ gamma,
-        const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int K, int a_blocked)
+        const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int K, int a_blocked, int dbg)
 {
-    __shared__ __attribute__((aligned(1024))) char lds[4 * LN_STAGE];
+    __shared__ __attribute__((aligned(1024))) char lds[4 * LN_STAGE + 3 * LN_N * 4];   // ring | bias, gamma, beta (fp32)
     static_assert(4 * LN_STAGE >= 4096 + 128 * LN_TS, "the epilogue parks the tile in the ring");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -610,7 +610,27 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
     // Slot = chunk ^ swz(row), swz(r) = (0 - (r >> 2)) & 3: with that the four 16-lane groups a
     // ds_read_b128 is served in (rows {0-3, 12-15} of one k-chunk and rows 4-11 of the next) each
     // touch all 64 banks once.  Wave w issues pieces 4w..4w+3 (waves 0, 1: the A rows).
-    const int nkt = K / 32;                                        // even (K is a multiple of 64)
+    const int nkt = K / 32;                                        // even (K is a multiple of 64), >= 12
+    // bias / gamma / beta live in LDS for the epilogue (36 dependent float4 global loads there cost microseconds per tile)
+    float* const prm = reinterpret_cast<float*>(lds + 4 * LN_STAGE);
+    if (threadIdx.x < 3 * LN_N / 4) {
+        const int which = threadIdx.x / (LN_N / 4), o = (threadIdx.x % (LN_N / 4)) * 4;
+        const float* srcp = which == 0 ? bias : which == 1 ? gamma : beta;
+        *reinterpret_cast<float4*>(prm + which * LN_N + o) = *reinterpret_cast<const float4*>(srcp + o);
+    }
+    // The residual rows (8 bytes per lane per accumulator block) are requested during the first
+    // stage and sit in registers until the epilogue: fetched there they cost ~5 us per tile.
+    uint2 rres[2][12];
+    auto prefetch_resid = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            int m = m0 + 32 * wm + 16 * mb + l15; if (m > M - 1) m = M - 1;
+            const uint16_t* rp = resid + (int64_t)m * LN_N + 192 * wn + 4 * g4;
+#pragma unroll
+            for (int nb = 0; nb < 12; ++nb)
+                asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(rres[mb][nb]) : "v"(rp), "n"(nb * 32));
+        }
+    };
     const int64_t rowbytes = (int64_t)K * 2;
     const char* src[4];
 #pragma unroll
@@ -628,7 +648,9 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
         else src[i] = reinterpret_cast<const char*>(W) + (int64_t)(r - 128) * 64 + ch * 16;          // W is packed [K / 32][384][32]
     }
     const int kstride = (wave < 2) ? (a_blocked ? 128 * 64 : 64) : LN_N * 64;               // A: 32 k further along the row; W: the next packed block
+    const bool dbg_skip = (wave < 2) ? (dbg & 1) : (dbg & 2);        // timing experiments only (MI_LN_DBG)
     auto issue = [&](int kt) __attribute__((always_inline)) {
+        if (dbg_skip) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[i] + (int64_t)kt * kstride),
@@ -681,8 +703,13 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
         rd_w(wf[P], kt, 2);
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[P ^ 1][0]), "+v"(wf[P ^ 1][1]), "+v"(wf[P ^ 1][2]), "+v"(wf[P ^ 1][3]));
         mma(wf[P ^ 1], a2, 1);
-        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // in flight behind stage kt + 1: stage kt + 2 (4 loads) and, in stage 1, the 24 residual loads
+        // (requested behind the barrier of stage 0; stage 2's wait retires them: they are older than stage 3)
+        if (kt == 1) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+        else if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (kt == 0) prefetch_resid();                             // younger than stages 0..2, older than stage 3
         if (kt + 3 < nkt) issue(kt + 3);
         if (kt + 1 < nkt) {
             rd_a(af[P ^ 1], kt + 1);
@@ -722,8 +749,8 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
 #pragma unroll
         for (int nb = 0; nb < 12; ++nb) {
             const int n = 192 * wn + 16 * nb + 4 * g4;
-            const float4 bv = *reinterpret_cast<const float4*>(bias + n);
-            const uint2 rv = *reinterpret_cast<const uint2*>(resid + (int64_t)m * LN_N + n);
+            const float4 bv = *reinterpret_cast<const float4*>(prm + n);
+            const uint2 rv = rres[mb][nb];
             acc[mb][nb][0] += bv.x + __builtin_bit_cast(float, rv.x << 16);
             acc[mb][nb][1] += bv.y + __builtin_bit_cast(float, rv.x & 0xFFFF0000u);
             acc[mb][nb][2] += bv.z + __builtin_bit_cast(float, rv.y << 16);
@@ -757,8 +784,8 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
 #pragma unroll
     for (int nb = 0; nb < 12; ++nb) {
         const int n = 192 * wn + 16 * nb + 4 * g4;
-        const float4 gv = *reinterpret_cast<const float4*>(gamma + n);
-        const float4 be = *reinterpret_cast<const float4*>(beta + n);
+        const float4 gv = *reinterpret_cast<const float4*>(prm + LN_N + n);
+        const float4 be = *reinterpret_cast<const float4*>(prm + 2 * LN_N + n);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const int ml = 32 * wm + 16 * mb + l15;
@@ -1215,6 +1242,7 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
     // hidden size 384: the two N = 384 projections run fused with their LayerNorm (MI_GEMM_LN=0: separate kernels)
     static const bool ln_off = getenv("MI_GEMM_LN") && atoi(getenv("MI_GEMM_LN")) == 0;
     const bool fused_ln = !ln_off && H == LN_N && I % 64 == 0;
+    static const int ln_dbg = getenv("MI_LN_DBG") ? atoi(getenv("MI_LN_DBG")) : 0;
     MI_HIP(hipEventRecord(e->ev0, st));
     if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
@@ -1222,7 +1250,7 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
         launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H);
         attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, scale_log2e);
         if (fused_ln) {
-            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(ctx, lw.Wo_p, lw.bo, h, lw.g1, lw.b1, c.layer_norm_eps, h, (int)T, H, 0);
+            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(ctx, lw.Wo_p, lw.bo, h, lw.g1, lw.b1, c.layer_norm_eps, h, (int)T, H, 0, ln_dbg);
         } else {
             launch_gemm<EPI_RESID>(st, ctx, lw.Wo, lw.bo, h, tmp, (int)T, H, H);
             if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
@@ -1230,7 +1258,7 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
         }
         const bool mid_blocked = launch_gemm<EPI_GELU>(st, h, lw.Wi, lw.bi, nullptr, mid, (int)T, I, H, fused_ln);
         if (fused_ln) {
-            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(mid, lw.Wd_p, lw.bd, h, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I, mid_blocked ? 1 : 0);
+            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(mid, lw.Wd_p, lw.bd, h, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I, mid_blocked ? 1 : 0, ln_dbg);
         } else {
             launch_gemm<EPI_RESID>(st, mid, lw.Wd, lw.bd, h, tmp, (int)T, H, I);
             if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
