@@ -433,15 +433,18 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
 
     // ---- LDS-DMA: wave w issues pieces 4w..4w+3 of a unit (4 rows x 256 B each)
     const int lr = lane >> 4, lt = lane & 15;
-    const unsigned sw0 = (unsigned)(lt ^ lr) << 4;
     auto tile_row0 = [&](int tl) { return (int64_t)(8 * (t_lo + tl) + xcd) * WS_TILE_R; };
-    const char* Ab = reinterpret_cast<const char*>(A) + (int64_t)(4 * wave * PPW + lr) * (K * 2);
+    // SGPR base + one 32-bit lane offset per piece (see search_mfma.hip: the builtin takes a 64-bit vector address)
+    const char* Ab = reinterpret_cast<const char*>(A) + (int64_t)(4 * wave * PPW) * (K * 2);
+    const unsigned voff0 = (unsigned)lr * (K * 2) + ((unsigned)(lt ^ lr) << 4);
+    const unsigned lds_base0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     auto issue_unit = [&](int tl, int kb, int buf) __attribute__((always_inline)) {
-        const int64_t off = tile_row0(tl) * (K * 2) + kb * 256;                  // rows past M: workspace slack, never stored
+        const char* ub = Ab + (tile_row0(tl) * (K * 2) + kb * 256);              // rows past M: workspace slack, never stored
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ab + (off + (int64_t)i * 4 * (K * 2)) + (sw0 ^ ((i & 3) << 6))),
-                (lds_ptr_t)(lds + buf * WS_STAGE + (wave * PPW + i) * 1024), 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(voff0 ^ ((unsigned)(i & 3) << 6)), "s"(ub + (int64_t)i * 4 * (K * 2)),
+                            "s"(lds_base0 + buf * WS_STAGE + (wave * PPW + i) * 1024) : "memory", "m0");
     };
 
     f32x4 acc[8][2];                                               // [16-row block of the tile][16-column block of the wave]
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
                     acc[4 * (t & 1) + r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        wq[KB * 4 + (t >> 1)][nb], a[t & 1][r], acc[4 * (t & 1) + r][nb], 0, 0, 0);
+                        wq[KB * 4 + (t >> 1)][nb], a[t & 1][r], (KB == 0 && t < 2) ? f32x4{} : acc[4 * (t & 1) + r][nb], 0, 0, 0);
         }
     };
 
@@ -556,12 +559,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
     }
     int u = 0;
     for (int tl = 0; tl < ntiles; ++tl) {
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[mb][nb][i] = 0.0f;
+        // (no clearing pass: the tile's first MFMA per accumulator takes C = 0)
         static_for<NKB>([&](auto KBc) __attribute__((always_inline)) {
             constexpr int kb = decltype(KBc)::value;
             if (u + 1 < nunits) issue_unit(tl + (kb + 1) / NKB, (kb + 1) % NKB, (u + 1) & 1);
