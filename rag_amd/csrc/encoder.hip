@@ -366,36 +366,40 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const uint16_t* __res
 }
 
 // ---------------------------------------------------------------- weight-stationary GEMM, K = 384
-// C[M][N] = A[M][384] * W[N][384]^T (+ epilogue) for the three projections whose reduction is the
-// hidden size (QKV, FFN1, attention output).  The 128x128 tile kernel above re-reads both
-// operands from L2 for every tile (64 flop per LDS-staged byte; measured: matrix pipe 33 % busy,
-// 12 TB/s of L2 traffic).  This one is the flat-search scan turned into a GEMM:
+// C[M][N] = A[M][384] * W[N][384]^T + bias (+ GELU) for the projections whose reduction is the hidden
+// size and whose N is large (QKV, FFN1).  The 128x128 tile kernel above re-reads both operands
+// from L2 for every tile (64 flop per LDS-staged byte).  This one is the flat-search scan turned
+// into a GEMM:
 //   * a workgroup of 8 waves owns 256 output columns; wave w keeps the W fragments of its 32
 //     columns x 384 in registers (96 VGPRs) for its whole life;
-//   * activation rows stream through LDS once per 256 columns, in units of 128 rows x 256 B,
-//     LDS-DMA, double-buffered, source-side swizzle — the scan's image, so 256 flop per byte;
+//   * activation rows stream through LDS once per 256 columns, in units of 128 rows x 256 B by
+//     LDS-DMA (SGPR base + 32-bit lane offset), ring of three, source-side swizzle;
 //   * v_mfma_f32_16x16x32_bf16 with the W fragment as the A operand: a lane owns one output row
-//     (lane & 15) and four consecutive columns per accumulator block, so bias / GELU are
-//     per-register and the tile is parked in LDS and leaves as whole 512-B row segments;
+//     (lane & 15) and four consecutive columns per accumulator block, so bias / GELU are per-register;
+//   * the workgroup barrier sits in the MIDDLE of a unit's chain and certifies the NEXT unit (as
+//     in the scan); unit u + 2 is requested right behind it.  Unit and tile boundaries are not
+//     synchronisation points, so the SIMD's two waves drift apart and one wave's epilogue (GELU:
+//     as many VALU cycles as the tile has MFMA cycles) runs behind the other's MFMAs;
+//   * the epilogue is wave-local: the wave parks its 128 x 32 slab (8 KB, swizzled) in its own LDS
+//     region and writes it out itself right behind the NEXT barrier, so the stores have a whole
+//     unit to retire before the following vmcnt(0).  BLK: C is [M / 128][N / 32][128][32] (what
+//     gemm_ln_kernel stages as whole 8-KB blocks) and a wave's slab is one contiguous block;
 //   * one workgroup per CU, placed by hand: the 32 workgroups of an XCD (blockIdx % 8) form
 //     floor(32 / G) row chunks x G column groups; the G groups of a chunk walk the same row
 //     tiles in step, so each activation tile comes from HBM once per XCD.
-// Waves whose columns lie beyond N only help with the loads and stores.
+// Waves whose columns lie beyond N only help with the loads.
 #define WS_TILE_R 128
 #define WS_STAGE (WS_TILE_R * 256)
-#define WS_PARK_OFF (2 * WS_STAGE)
-#define WS_TS16 528                 // parked bf16 row: 256 columns + 8 pad
-#define WS_TS32 1056                // parked fp32 row (64 rows at a time)
-#define WS_LDS_BYTES (WS_PARK_OFF + 128 * WS_TS16)
+#define WS_PARK_OFF (3 * WS_STAGE)
+#define WS_LDS_BYTES (WS_PARK_OFF + 8 * 8192)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int EPI, bool BLK>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
-        const float* __restrict__ bias, const uint16_t* __restrict__ resid, uint16_t* __restrict__ C,
-        int M, int N, int n_groups, int n_chunks)
+        const float* __restrict__ bias, uint16_t* __restrict__ C, int M, int N, int n_groups, int n_chunks)
 {
     constexpr int K = 384, NKB = 3, PPW = 4;
-    static_assert(128 * WS_TS16 == 64 * WS_TS32, "one park buffer for both forms");
+    static_assert(EPI == EPI_BIAS || EPI == EPI_GELU, "the residual epilogue lives in gemm_ln_kernel / gemm_bf16_kernel");
     __shared__ __attribute__((aligned(1024))) char lds[WS_LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -430,28 +434,27 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
         bv[0] = *reinterpret_cast<const float4*>(bias + n0 + wave * 32 + 4 * g4);
         bv[1] = *reinterpret_cast<const float4*>(bias + n0 + wave * 32 + 16 + 4 * g4);
     }
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(bv[0].x), "v"(bv[1].x) : "memory");
 
-    // ---- LDS-DMA: wave w issues pieces 4w..4w+3 of a unit (4 rows x 256 B each)
+    // ---- LDS-DMA: wave w issues pieces 4w..4w+3 of a unit (4 rows x 256 B each); unit (tile, kb) -> ring buffer kb
     const int lr = lane >> 4, lt = lane & 15;
     auto tile_row0 = [&](int tl) { return (int64_t)(8 * (t_lo + tl) + xcd) * WS_TILE_R; };
-    // SGPR base + one 32-bit lane offset per piece (see search_mfma.hip: the builtin takes a 64-bit vector address)
     const char* Ab = reinterpret_cast<const char*>(A) + (int64_t)(4 * wave * PPW) * (K * 2);
     const unsigned voff0 = (unsigned)lr * (K * 2) + ((unsigned)(lt ^ lr) << 4);
-    const unsigned lds_base0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-    auto issue_unit = [&](int tl, int kb, int buf) __attribute__((always_inline)) {
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    auto issue_unit = [&](int tl, int kb) __attribute__((always_inline)) {
         const char* ub = Ab + (tile_row0(tl) * (K * 2) + kb * 256);              // rows past M: workspace slack, never stored
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                          :: "v"(voff0 ^ ((unsigned)(i & 3) << 6)), "s"(ub + (int64_t)i * 4 * (K * 2)),
-                            "s"(lds_base0 + buf * WS_STAGE + (wave * PPW + i) * 1024) : "memory", "m0");
+                            "s"(lds_base + kb * WS_STAGE + (wave * PPW + i) * 1024) : "memory", "m0");
     };
 
     f32x4 acc[8][2];                                               // [16-row block of the tile][16-column block of the wave]
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-    auto chain = [&](int buf, auto KBc) __attribute__((always_inline)) {
+    auto chain = [&](auto KBc, auto&& mid) __attribute__((always_inline)) {
         constexpr int KB = decltype(KBc)::value;
-        const unsigned cur = (lds_base + buf * WS_STAGE + l15 * 256) | ((unsigned)(g4 ^ l15) << 4);
+        const unsigned cur = (lds_base + KB * WS_STAGE + l15 * 256) | ((unsigned)(g4 ^ l15) << 4);
         bf16x8 a[2][4];
         auto rd = [&](bf16x8 (&f)[4], int grp) __attribute__((always_inline)) {
             const unsigned ad = cur ^ ((unsigned)(grp >> 1) << 6);
@@ -476,100 +479,89 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < 2; ++nb)             // the tile's first MFMA per accumulator takes C = 0: no clearing pass
                     acc[4 * (t & 1) + r][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         wq[KB * 4 + (t >> 1)][nb], a[t & 1][r], (KB == 0 && t < 2) ? f32x4{} : acc[4 * (t & 1) + r][nb], 0, 0, 0);
+            if (t == 3) mid();
         }
     };
 
-    // ---- epilogue of one tile: the lane holds, for row 16 mb + l15, columns 32 w + 16 nb + 4 g4 + (0..3)
-    char* park = lds + WS_PARK_OFF;
-    auto epilogue = [&](int tl) __attribute__((always_inline)) {
+    // ---- epilogue, phase 1 (end of a tile): bias (+ GELU), bf16, into the wave's own slab: row r at r * 64,
+    // 8-byte slot (4 nb + g4) ^ 2 ((r >> 2) & 3)  (16 rows x 8 B per ds_write group: all 32 bank pairs once)
+    // (r >> 2) & 3 does not depend on the 16-row block, so every address is one lane constant plus an
+    // immediate: as separate loop invariants the 24 addresses are hoisted and spilled.
+    const unsigned park = lds_base + WS_PARK_OFF + wave * 8192;
+    unsigned pk_w0 = park + l15 * 64 + (((unsigned)g4 ^ ((((unsigned)l15 >> 2) & 3) << 1)) << 3);       // nb = 0; nb = 1: ^ 32
+    auto park_tile = [&]() __attribute__((always_inline)) {
+        static_for<8>([&](auto MBc) __attribute__((always_inline)) {
+            constexpr int mb = decltype(MBc)::value;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const f32x4 v = acc[mb][nb];
+                float v0 = v[0] + bv[nb].x, v1 = v[1] + bv[nb].y, v2 = v[2] + bv[nb].z, v3 = v[3] + bv[nb].w;
+                if constexpr (EPI == EPI_GELU) gelu_erf4(v0, v1, v2, v3);
+                const uint2 o = make_uint2(pack2(v0, v1), pack2(v2, v3));
+                const unsigned adw = pk_w0 ^ (nb ? 32u : 0u);
+                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(adw), "v"(o), "n"(mb * 1024) : "memory");
+            }
+        });
+    };
+    // ---- phase 2 (behind the next tile's first unit): the slab leaves as 16-byte chunks, lane -> row lane / 4 + 16 p, chunk lane % 4
+    auto store_tile = [&](int tl) __attribute__((always_inline)) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const int64_t m_base = tile_row0(tl);
-        const int r0 = threadIdx.x >> 5, ch = threadIdx.x & 31;      // store phase: row r0 + 16 p, 16-B chunk ch (8 columns)
-        const bool col_ok = n0 + 8 * ch < N;
-        if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {                   // fp32 park, 64 rows at a time: one rounding, after the residual
-                if (active) {
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) {
-                            const f32x4 v = acc[4 * half + mb][nb];
-                            *reinterpret_cast<float4*>(park + (16 * mb + l15) * WS_TS32 + (wave * 32 + 16 * nb + 4 * g4) * 4) =
-                                make_float4(v[0] + bv[nb].x, v[1] + bv[nb].y, v[2] + bv[nb].z, v[3] + bv[nb].w);
-                        }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int r = r0 + 16 * p;
-                    const int64_t m = m_base + 64 * half + r;
-                    if (m < M && col_ok) {
-                        const float4 x0 = *reinterpret_cast<const float4*>(park + r * WS_TS32 + ch * 32);
-                        const float4 x1 = *reinterpret_cast<const float4*>(park + r * WS_TS32 + ch * 32 + 16);
-                        const uint4 rv = *reinterpret_cast<const uint4*>(resid + m * N + n0 + 8 * ch);
-                        uint4 o;
-                        o.x = pack2(x0.x + __builtin_bit_cast(float, rv.x << 16), x0.y + __builtin_bit_cast(float, rv.x & 0xFFFF0000u));
-                        o.y = pack2(x0.z + __builtin_bit_cast(float, rv.y << 16), x0.w + __builtin_bit_cast(float, rv.y & 0xFFFF0000u));
-                        o.z = pack2(x1.x + __builtin_bit_cast(float, rv.z << 16), x1.y + __builtin_bit_cast(float, rv.z & 0xFFFF0000u));
-                        o.w = pack2(x1.z + __builtin_bit_cast(float, rv.w << 16), x1.w + __builtin_bit_cast(float, rv.w & 0xFFFF0000u));
-                        *reinterpret_cast<uint4*>(C + m * N + n0 + 8 * ch) = o;
-                    }
-                }
-                __syncthreads();
+        const unsigned rr = (unsigned)lane >> 2, c = (unsigned)lane & 3;
+        unsigned pk_r = park + rr * 64 + ((c ^ ((rr >> 2) & 3)) << 4);
+        // one contiguous 8-KB block when BLK; rows past M lie in the padded last tile of the blocked buffer
+        // wave-uniform base + a lane offset formed here (as loop invariants the 64-bit lane pointers get spilled)
+        unsigned l4;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 2, %0" : "=v"(l4));
+        const uint16_t* const ubase = BLK ? C + ((m_base >> 7) * (N >> 5) + (n0 >> 5) + wave) * 4096
+                                          : C + m_base * N + n0 + wave * 32;
+        uint16_t* const blk = const_cast<uint16_t*>(ubase) + (BLK ? (size_t)(l4 * 2)                       // lane * 8 elements
+                                                                  : (size_t)((l4 >> 4) * (unsigned)N + ((l4 >> 2) & 3u) * 8u));
+        static_for<4>([&](auto Pc) __attribute__((always_inline)) {
+            constexpr int p = 2 * decltype(Pc)::value;             // two chunks at a time
+            u32x4 o0, o1;
+            const unsigned adr = pk_r;
+            asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(o0), "=&v"(o1) : "v"(adr), "n"(p * 1024), "n"((p + 1) * 1024) : "memory");
+            if constexpr (BLK) {
+                *reinterpret_cast<u32x4*>(blk + p * 512) = o0;
+                *reinterpret_cast<u32x4*>(blk + (p + 1) * 512) = o1;
+            } else {
+                if (m_base + rr + 16 * p < M) *reinterpret_cast<u32x4*>(blk + (int64_t)16 * p * N) = o0;
+                if (m_base + rr + 16 * (p + 1) < M) *reinterpret_cast<u32x4*>(blk + (int64_t)16 * (p + 1) * N) = o1;
             }
-        } else {
-            if (active) {
-#pragma unroll
-                for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) {
-                        const f32x4 v = acc[mb][nb];
-                        float v0 = v[0] + bv[nb].x, v1 = v[1] + bv[nb].y, v2 = v[2] + bv[nb].z, v3 = v[3] + bv[nb].w;
-                        if constexpr (EPI == EPI_GELU) gelu_erf4(v0, v1, v2, v3);
-                        *reinterpret_cast<uint2*>(park + (16 * mb + l15) * WS_TS16 + (wave * 32 + 16 * nb + 4 * g4) * 2) =
-                            make_uint2(pack2(v0, v1), pack2(v2, v3));
-                    }
-            }
-            __syncthreads();
-            // one base per tile, then a constant 1-KB step per row group (rows r0 + 16 p of the 32-column block)
-            uint16_t* const blk_base = C + ((((m_base >> 7) * (N >> 5) + (n0 >> 5) + (ch >> 2)) * 128 + r0) * 32 + (ch & 3) * 8);
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const int r = r0 + 16 * p;
-                const int64_t m = m_base + r;
-                // BLK: rows past M lie in the padded last tile of the blocked buffer (never read back as results)
-                if ((BLK || m < M) && col_ok) {
-                    // BLK: C is [M / 128][N / 32][128][32] (what gemm_ln_kernel stages as whole 8-KB blocks)
-                    uint16_t* dst = BLK ? blk_base + p * 512 : C + m * N + n0 + 8 * ch;
-                    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(park + r * WS_TS16 + ch * 16);
-                }
-            }
-            // the next park write is three unit barriers away
-        }
+        });
     };
 
-    // ---- main loop: double-buffered units, one barrier each (the scan's PD = 1 form)
+    // ---- main loop.  At the barrier of unit u: unit u + 1 has landed for everyone (it was requested
+    // behind the barrier of unit u - 1), everyone has left unit u - 1, whose buffer takes unit u + 2.
+    // vmcnt(0) also retires the previous tile's stores; they were issued one whole unit earlier.
     if (nunits > 0) {
-        issue_unit(0, 0, 0);
+        issue_unit(0, 0);
+        if (nunits > 1) issue_unit(1 / NKB, 1 % NKB);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
     int u = 0;
     for (int tl = 0; tl < ntiles; ++tl) {
-        // (no clearing pass: the tile's first MFMA per accumulator takes C = 0)
         static_for<NKB>([&](auto KBc) __attribute__((always_inline)) {
             constexpr int kb = decltype(KBc)::value;
-            if (u + 1 < nunits) issue_unit(tl + (kb + 1) / NKB, (kb + 1) % NKB, (u + 1) & 1);
-            if (active) chain(u & 1, IC<kb>{});
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            auto mid = [&]() __attribute__((always_inline)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (u + 2 < nunits) issue_unit(tl + (kb + 2) / NKB, (kb + 2) % NKB);
+            };
+            if (active) chain(IC<kb>{}, mid); else mid();
+            // the previous tile's slab leaves behind the first unit of this one (inside the chain there is no register to spare)
+            if constexpr (kb == 0) { if (active && tl > 0) store_tile(tl - 1); }
+            if constexpr (kb == NKB - 1) { if (active) park_tile(); }
             ++u;
         });
-        epilogue(tl);
     }
+    if (active && ntiles > 0) store_tile(ntiles - 1);
 }
 
 // ---------------------------------------------------------------- row-complete GEMM + bias + residual + LayerNorm, N = 384
@@ -1185,15 +1177,17 @@ static bool launch_gemm_ws(hipStream_t st, const uint16_t* A, const uint16_t* W,
 {
     static const bool off = getenv("MI_GEMM_WS") && atoi(getenv("MI_GEMM_WS")) == 0;
     // N = 384 (attention output) fills only 1.5 column groups: measured slower than the tile kernel
-    if (off || K != 384 || N % 32 != 0 || N < 512 || M < 16384) return false;
+    if (off || EPI == EPI_RESID || K != 384 || N % 32 != 0 || N < 512 || M < 16384) return false;
     const int n_groups = (N + 255) / 256;
     if (n_groups > 32) return false;
     const int m_tiles = (M + WS_TILE_R - 1) / WS_TILE_R;
     int n_chunks = 32 / n_groups;
     if (n_chunks > m_tiles / 8) n_chunks = m_tiles / 8;
     if (n_chunks < 1) return false;
-    if (blocked_out && EPI != EPI_RESID) gemm_ws_kernel<EPI, true><<<256, 512, 0, st>>>(A, W, bias, resid, C, M, N, n_groups, n_chunks);
-    else gemm_ws_kernel<EPI, false><<<256, 512, 0, st>>>(A, W, bias, resid, C, M, N, n_groups, n_chunks);
+    if constexpr (EPI != EPI_RESID) {
+        if (blocked_out) gemm_ws_kernel<EPI, true><<<256, 512, 0, st>>>(A, W, bias, C, M, N, n_groups, n_chunks);
+        else gemm_ws_kernel<EPI, false><<<256, 512, 0, st>>>(A, W, bias, C, M, N, n_groups, n_chunks);
+    }
     return true;
 }
 
@@ -1202,7 +1196,7 @@ static bool launch_gemm(hipStream_t st, const uint16_t* A, const uint16_t* W, co
                         uint16_t* C, int M, int N, int K, bool want_blocked = false)
 {
     // returns true iff C was written in the blocked layout (only the weight-stationary kernel can)
-    if (launch_gemm_ws<EPI>(st, A, W, bias, resid, C, M, N, K, want_blocked)) return want_blocked && EPI != EPI_RESID;
+    if (launch_gemm_ws<EPI>(st, A, W, bias, resid, C, M, N, K, want_blocked)) return want_blocked;
     const int n_tiles = N / GM_BN, m_tiles = (M + GM_BM - 1) / GM_BM;
     const unsigned grid = (unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles);
     gemm_bf16_kernel<EPI><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K, n_tiles, m_tiles);
