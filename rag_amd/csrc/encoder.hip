@@ -887,27 +887,38 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
             // scores in log2 units: s * (dh^-1/2 * log2 e) + mask, mask = 0 or -FLT_MAX (finite, as in
             // the reference's additive finfo.min mask: the fma leaves a masked score at -FLT_MAX, so an
             // all-masked row softmaxes to uniform)
-            float tv[16];
+            // (two values per instruction where the ISA has a packed fp32 form: the kernel is VALU-bound)
+            f32x2 t2[8];
+            const f32x2 sc2 = {scale_log2e, scale_log2e};
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float mkv = (i & 3) == 0 ? mk[i >> 2].x : (i & 3) == 1 ? mk[i >> 2].y : (i & 3) == 2 ? mk[i >> 2].z : mk[i >> 2].w;
-                tv[i] = __builtin_fmaf(S[i], scale_log2e, mkv);
+            for (int i = 0; i < 8; ++i) {
+                const f32x2 s2 = {S[2 * i], S[2 * i + 1]};
+                const f32x2 m2 = (i & 1) ? f32x2{mk[i >> 1].z, mk[i >> 1].w} : f32x2{mk[i >> 1].x, mk[i >> 1].y};
+                t2[i] = __builtin_elementwise_fma(s2, sc2, m2);
             }
-            float bm = __builtin_fmaxf(__builtin_fmaxf(tv[0], tv[1]), tv[2]);
+            float bm = __builtin_fmaxf(__builtin_fmaxf(t2[0].x, t2[0].y), t2[1].x);
+            bm = __builtin_fmaxf(__builtin_fmaxf(bm, t2[1].y), t2[2].x);
 #pragma unroll
-            for (int i = 3; i < 15; i += 2) bm = __builtin_fmaxf(__builtin_fmaxf(bm, tv[i]), tv[i + 1]);
-            bm = __builtin_fmaxf(bm, tv[15]);
+            for (int i = 2; i < 7; ++i) bm = __builtin_fmaxf(__builtin_fmaxf(bm, t2[i].y), t2[i + 1].x);
+            bm = __builtin_fmaxf(bm, t2[7].y);
             bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
             const float m_new = fmaxf(m_run[nb], bm);
             const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_new);
-            float ps = 0.0f;
+            const f32x2 mn2 = {m_new, m_new};
+            f32x2 ps2 = {0.0f, 0.0f};
             float p[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { p[i] = __builtin_amdgcn_exp2f(tv[i] - m_new); ps += p[i]; }
-            l_run[nb] = l_run[nb] * alpha + ps;
+            for (int i = 0; i < 8; ++i) {
+                const f32x2 d2 = t2[i] - mn2;
+                f32x2 e2;
+                e2.x = __builtin_amdgcn_exp2f(d2.x);
+                e2.y = __builtin_amdgcn_exp2f(d2.y);
+                ps2 = ps2 + e2;
+                p[2 * i] = e2.x; p[2 * i + 1] = e2.y;
+            }
+            l_run[nb] = l_run[nb] * alpha + (ps2.x + ps2.y);
             m_run[nb] = m_new;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) O[nb][i] *= alpha;
+            O[nb] = O[nb] * alpha;
             // P^T as B operand: k-step s takes registers 8 s .. 8 s + 7
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
