@@ -396,7 +396,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int EPI, bool BLK>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
-        const float* __restrict__ bias, uint16_t* __restrict__ C, int M, int N, int n_groups, int n_chunks)
+        const float* __restrict__ bias, uint16_t* __restrict__ C, int M, int N, int n_full, int chunks_full, int chunks_tail)
 {
     constexpr int K = 384, NKB = 3, PPW = 4;
     static_assert(EPI == EPI_BIAS || EPI == EPI_GELU, "the residual epilogue lives in gemm_ln_kernel / gemm_bf16_kernel");
@@ -407,8 +407,14 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
 
     // placement: XCD = blockIdx % 8 (round-robin dispatch); k-th workgroup of the XCD
     const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
-    if (kx >= n_groups * n_chunks) return;                         // spare CUs of this XCD
-    const int chunk = kx / n_groups, ng = kx % n_groups;
+    // n_full column groups of 256 get chunks_full row chunks each; a last, narrower group (N % 256
+    // columns, some waves idle) gets chunks_tail: fewer, longer chunks, so that its workgroups finish
+    // with the others instead of leaving their CUs half used
+    if (kx >= n_full * chunks_full + chunks_tail) return;          // spare CUs of this XCD
+    const bool tail = kx >= n_full * chunks_full;
+    const int chunk = tail ? kx - n_full * chunks_full : kx / n_full;
+    const int ng = tail ? n_full : kx % n_full;
+    const int n_chunks = tail ? chunks_tail : chunks_full;
     const int m_tiles = (M + WS_TILE_R - 1) / WS_TILE_R;
     const int tiles_x = (m_tiles - xcd + 7) / 8;                   // row tiles xcd, xcd + 8, ... of this XCD
     const int t_lo = (int)((int64_t)tiles_x * chunk / n_chunks), t_hi = (int)((int64_t)tiles_x * (chunk + 1) / n_chunks);
@@ -1189,15 +1195,27 @@ static bool launch_gemm_ws(hipStream_t st, const uint16_t* A, const uint16_t* W,
     static const bool off = getenv("MI_GEMM_WS") && atoi(getenv("MI_GEMM_WS")) == 0;
     // N = 384 (attention output) fills only 1.5 column groups: measured slower than the tile kernel
     if (off || EPI == EPI_RESID || K != 384 || N % 32 != 0 || N < 512 || M < 16384) return false;
-    const int n_groups = (N + 255) / 256;
-    if (n_groups > 32) return false;
+    const int n_full = N / 256, has_tail = (N % 256) ? 1 : 0;
+    const int n_groups = n_full + has_tail;
+    if (n_groups > 32 || n_full < 1) return false;
     const int m_tiles = (M + WS_TILE_R - 1) / WS_TILE_R;
-    int n_chunks = 32 / n_groups;
-    if (n_chunks > m_tiles / 8) n_chunks = m_tiles / 8;
-    if (n_chunks < 1) return false;
+    // 32 CUs per XCD: x chunks for each full group, y for the tail group, n_full x + y <= 32, minimising the
+    // longer of the two (a tail workgroup takes about 0.6 of the time per row tile: same stream, half the MFMAs)
+    int cf = 32 / n_groups, ct = has_tail ? cf : 0;
+    if (has_tail) {
+        double best = 1.0 / cf;
+        for (int x = cf; x <= 32; ++x) {
+            const int y = 32 - n_full * x;
+            if (y < 1) break;
+            const double cost = (1.0 / x > 0.6 / y) ? 1.0 / x : 0.6 / y;
+            if (cost < best - 1e-9) { best = cost; cf = x; ct = y; }
+        }
+    }
+    if (cf > m_tiles / 8) { cf = m_tiles / 8; if (has_tail && ct > cf) ct = cf; }
+    if (cf < 1 || (has_tail && ct < 1)) return false;
     if constexpr (EPI != EPI_RESID) {
-        if (blocked_out) gemm_ws_kernel<EPI, true><<<256, 512, 0, st>>>(A, W, bias, C, M, N, n_groups, n_chunks);
-        else gemm_ws_kernel<EPI, false><<<256, 512, 0, st>>>(A, W, bias, C, M, N, n_groups, n_chunks);
+        if (blocked_out) gemm_ws_kernel<EPI, true><<<256, 512, 0, st>>>(A, W, bias, C, M, N, n_full, cf, ct);
+        else gemm_ws_kernel<EPI, false><<<256, 512, 0, st>>>(A, W, bias, C, M, N, n_full, cf, ct);
     }
     return true;
 }
