@@ -588,7 +588,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
 
 __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         const float* __restrict__ bias, const uint16_t* __restrict__ resid, const float* __restrict__ gamma,
-        const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int K, int a_blocked, int dbg)
+        const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int K, int a_blocked)
 {
     __shared__ __attribute__((aligned(1024))) char lds[4 * LN_STAGE + 3 * LN_N * 4];   // ring | bias, gamma, beta (fp32)
     static_assert(4 * LN_STAGE >= 4096 + 128 * LN_TS, "the epilogue parks the tile in the ring");
@@ -644,9 +644,7 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
         else src[i] = reinterpret_cast<const char*>(W) + (int64_t)(r - 128) * 64 + ch * 16;          // W is packed [K / 32][384][32]
     }
     const int kstride = (wave < 2) ? (a_blocked ? 128 * 64 : 64) : LN_N * 64;               // A: 32 k further along the row; W: the next packed block
-    const bool dbg_skip = (wave < 2) ? (dbg & 1) : (dbg & 2);        // timing experiments only (MI_LN_DBG)
     auto issue = [&](int kt) __attribute__((always_inline)) {
-        if (dbg_skip) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[i] + (int64_t)kt * kstride),
@@ -807,7 +805,7 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
 // in-register plus one cross-half exchange; P (bf16) feeds O^T = V^T P^T directly as the B
 // operand (the accumulator-as-operand k-permutation is matched by the V^T fragment reads).
 __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
-        uint16_t* __restrict__ ctx, int L, int Lp, int H, float scale_log2e)
+        uint16_t* __restrict__ ctx, int L, int Lp, int H, float scale_log2e, int qkv_blocked, int ctx_blocked)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // Ks [Lp][64 B] swizzled | Vt [32][Lp*2 + 8 B] | maskf [Lp]
@@ -822,13 +820,24 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
     const int head = blockIdx.x, b = blockIdx.y;
     const int H3 = 3 * H;
     const uint16_t* base = qkv + (int64_t)b * L * H3 + head * 32;
+    // blocked layouts ([tokens / 128][columns / 32][128][32], written by gemm_ws_kernel / read by
+    // gemm_ln_kernel): the 32 columns of a head are one column block, 128 tokens of it one 8-KB block
+    const int64_t tok0 = (int64_t)b * L;
+    const int nblk_q = H3 >> 5, nblk_c = H >> 5;
+    auto qkv_at = [&](int key, int which, int c) -> const uint16_t* {     // which: 0 Q, 1 K, 2 V; c: 8-column chunk
+        if (qkv_blocked) {
+            const int64_t tg = tok0 + key;
+            return qkv + (((tg >> 7) * nblk_q + which * nblk_c + head) * 128 + (tg & 127)) * 32 + c * 8;
+        }
+        return base + (int64_t)key * H3 + which * H + c * 8;
+    };
 
     for (int idx = t; idx < Lp * 4; idx += 256) {
         const int key = idx >> 2, c = idx & 3;
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
         if (key < L) {
-            kv = *reinterpret_cast<const uint4*>(base + (int64_t)key * H3 + H + c * 8);
-            vv = *reinterpret_cast<const uint4*>(base + (int64_t)key * H3 + 2 * H + c * 8);
+            kv = *reinterpret_cast<const uint4*>(qkv_at(key, 1, c));
+            vv = *reinterpret_cast<const uint4*>(qkv_at(key, 2, c));
         }
         *reinterpret_cast<uint4*>(Ks + key * 64 + ((c ^ ((key >> 2) & 3)) << 4)) = kv;
         const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
@@ -852,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
         if (q > L - 1) q = L - 1;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-            qf[nb][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + (int64_t)q * H3 + 16 * s + 8 * hp));
+            qf[nb][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qkv_at(q, 0, 2 * s + hp)));
     }
     float m_run[2] = {-__builtin_inff(), -__builtin_inff()};
     float l_run[2] = {0.0f, 0.0f};
@@ -940,7 +949,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
         const float lt = l_run[nb] + __shfl_xor(l_run[nb], 32, 64);
         const float inv = 1.0f / lt;
         if (q < L) {
-            uint16_t* dst = ctx + ((int64_t)b * L + q) * H + head * 32;
+            const int64_t tg = tok0 + q;
+            uint16_t* dst = ctx_blocked ? ctx + (((tg >> 7) * nblk_c + head) * 128 + (tg & 127)) * 32
+                                        : ctx + tg * H + head * 32;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {       // dh = 8 g + 4 hp + (0..3)
                 uint2 o;
@@ -1263,15 +1274,14 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
     // hidden size 384: the two N = 384 projections run fused with their LayerNorm (MI_GEMM_LN=0: separate kernels)
     static const bool ln_off = getenv("MI_GEMM_LN") && atoi(getenv("MI_GEMM_LN")) == 0;
     const bool fused_ln = !ln_off && H == LN_N && I % 64 == 0;
-    static const int ln_dbg = getenv("MI_LN_DBG") ? atoi(getenv("MI_LN_DBG")) : 0;
     MI_HIP(hipEventRecord(e->ev0, st));
     if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     for (const LayerW& lw : e->layers) {
-        launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H);
-        attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, scale_log2e);
+        const bool qkv_blocked = launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H, true);
+        attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, scale_log2e, qkv_blocked ? 1 : 0, fused_ln ? 1 : 0);
         if (fused_ln) {
-            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(ctx, lw.Wo_p, lw.bo, h, lw.g1, lw.b1, c.layer_norm_eps, h, (int)T, H, 0, ln_dbg);
+            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(ctx, lw.Wo_p, lw.bo, h, lw.g1, lw.b1, c.layer_norm_eps, h, (int)T, H, 1);
         } else {
             launch_gemm<EPI_RESID>(st, ctx, lw.Wo, lw.bo, h, tmp, (int)T, H, H);
             if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
@@ -1279,7 +1289,7 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
         }
         const bool mid_blocked = launch_gemm<EPI_GELU>(st, h, lw.Wi, lw.bi, nullptr, mid, (int)T, I, H, fused_ln);
         if (fused_ln) {
-            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(mid, lw.Wd_p, lw.bd, h, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I, mid_blocked ? 1 : 0, ln_dbg);
+            gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(mid, lw.Wd_p, lw.bd, h, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I, mid_blocked ? 1 : 0);
         } else {
             launch_gemm<EPI_RESID>(st, mid, lw.Wd, lw.bd, h, tmp, (int)T, H, I);
             if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
