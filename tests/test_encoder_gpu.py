@@ -124,3 +124,20 @@ def test_large_batch_takes_the_weight_stationary_gemm(oracle_mod):
     cos = (E[sel] * Eo).sum(1) / (np.linalg.norm(E[sel], axis=1) * np.linalg.norm(Eo, axis=1))
     assert np.all(1.0 - cos < 1e-3), 1.0 - cos
     assert np.all(np.isfinite(E))
+
+
+def test_hidden_768_takes_the_general_kernels(oracle_mod):
+    """hidden 768 (24 heads of 32): two-chunk LayerNorm / embedding / pool kernels, the tile GEMM and the
+    separate add + LayerNorm path (the fused N = 384 kernels do not apply)."""
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import random_blob
+    cfg, ocfg = _cfgs(oracle_mod, 1000, 768, 2, 24, 3072, 128, 2, 1e-12, 1)
+    blob = random_blob(cfg, seed=5, init_range=0.03)
+    rng = np.random.default_rng(11)
+    ids = rng.integers(0, 1000, size=(4, 77)).astype(np.int32)
+    mask = np.ones((4, 77), dtype=np.int32)
+    mask[1, 30:] = 0
+    mask[3, 1:] = 0
+    E = Encoder(cfg, blob).encode_ids(ids, mask)
+    Eo = oracle_mod.encode(ocfg, blob, ids, mask)
+    assert np.all(_cos_err(E, Eo) < TOL), _cos_err(E, Eo)
