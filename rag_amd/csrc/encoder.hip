@@ -570,6 +570,81 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
     if (active && ntiles > 0) store_tile(ntiles - 1);
 }
 
+#define LN_N 384
+#define LN_TS 784                            // parked bf16 row: 384 columns + 8 pad
+// ---- shared epilogue of the row-complete kernels: bias + residual, LayerNorm over the 384 columns, bf16 rows out.
+// The lane holds, for rows m = m0 + 32 wm + 16 mb + l15, columns 192 wn + 16 nb + 4 g4 + (0..3).
+// lds: >= 4096 + 128 * LN_TS bytes of scratch nobody else touches any more; prm: bias | gamma | beta (fp32, LDS).
+__device__ __forceinline__ void ln_rows_epilogue(char* lds, const float* prm, f32x4 (&acc)[2][12], const uint2 (&rres)[2][12],
+        uint16_t* __restrict__ out, int m0, int M, float eps, int wm, int wn, int l15, int g4)
+{
+    float* rs = reinterpret_cast<float*>(lds);                 // [2 passes][2 column halves][128 rows] row sums
+    char* park = lds + 4096;
+    float mean[2], inv[2];
+    // bias + residual (8-byte loads: 4 consecutive columns of the lane's row), row sum
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int ml = 32 * wm + 16 * mb + l15;
+        float sum = 0.0f;
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb) {
+            const int n = 192 * wn + 16 * nb + 4 * g4;
+            const float4 bv = *reinterpret_cast<const float4*>(prm + n);
+            const uint2 rv = rres[mb][nb];
+            acc[mb][nb][0] += bv.x + __builtin_bit_cast(float, rv.x << 16);
+            acc[mb][nb][1] += bv.y + __builtin_bit_cast(float, rv.x & 0xFFFF0000u);
+            acc[mb][nb][2] += bv.z + __builtin_bit_cast(float, rv.y << 16);
+            acc[mb][nb][3] += bv.w + __builtin_bit_cast(float, rv.y & 0xFFFF0000u);
+            sum += (acc[mb][nb][0] + acc[mb][nb][1]) + (acc[mb][nb][2] + acc[mb][nb][3]);
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (g4 == 0) rs[wn * 128 + ml] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int ml = 32 * wm + 16 * mb + l15;
+        mean[mb] = (rs[ml] + rs[128 + ml]) * (1.0f / LN_N);
+        float sq = 0.0f;
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float dlt = acc[mb][nb][i] - mean[mb]; sq += dlt * dlt; }
+        sq += __shfl_xor(sq, 16, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        if (g4 == 0) rs[256 + wn * 128 + ml] = sq;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int ml = 32 * wm + 16 * mb + l15;
+        inv[mb] = 1.0f / sqrtf((rs[256 + ml] + rs[384 + ml]) * (1.0f / LN_N) + eps);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 12; ++nb) {
+        const int n = 192 * wn + 16 * nb + 4 * g4;
+        const float4 gv = *reinterpret_cast<const float4*>(prm + LN_N + n);
+        const float4 be = *reinterpret_cast<const float4*>(prm + 2 * LN_N + n);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int ml = 32 * wm + 16 * mb + l15;
+            const float y0 = (acc[mb][nb][0] - mean[mb]) * inv[mb] * gv.x + be.x, y1 = (acc[mb][nb][1] - mean[mb]) * inv[mb] * gv.y + be.y;
+            const float y2 = (acc[mb][nb][2] - mean[mb]) * inv[mb] * gv.z + be.z, y3 = (acc[mb][nb][3] - mean[mb]) * inv[mb] * gv.w + be.w;
+            *reinterpret_cast<uint2*>(park + ml * LN_TS + n * 2) = make_uint2(pack2(y0, y1), pack2(y2, y3));
+        }
+    }
+    __syncthreads();
+    // whole 768-B rows out: thread t takes 16-B chunk t % 48 of rows t / 48 + 10 p (480 of the 512 threads)
+    if (threadIdx.x < 480) {
+        const int r0 = threadIdx.x / 48, ch = threadIdx.x % 48;
+        for (int r = r0; r < 128; r += 10) {
+            const int m = m0 + r;
+            if (m < M) *reinterpret_cast<uint4*>(out + (int64_t)m * LN_N + 8 * ch) = *reinterpret_cast<const uint4*>(park + r * LN_TS + ch * 16);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- row-complete GEMM + bias + residual + LayerNorm, N = 384
 // out[M][384] = LayerNorm(A[M][K] * W[384][K]^T + bias + resid) * gamma + beta   (modeling_bert.py:289-293, :347-351)
 // for the attention output (K = 384) and FFN output (K = 1536) projections.  One workgroup of
@@ -582,9 +657,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
 // the finished tile is parked in LDS and leaves as whole 768-B rows.  Stages of 32 k (A 8 KB +
 // W 24 KB) by LDS-DMA in a ring of four, requested three stages ahead.
 // `out` may alias `resid`: a workgroup reads and writes only its own rows.
-#define LN_N 384
 #define LN_STAGE (512 * 64)                  // 128 A rows + 384 W rows, 64 B (32 k) each
-#define LN_TS 784                            // parked bf16 row: 384 columns + 8 pad
 
 __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         const float* __restrict__ bias, const uint16_t* __restrict__ resid, const float* __restrict__ gamma,
@@ -730,73 +803,218 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
     }
     __syncthreads();                                               // the ring becomes the epilogue's scratch
 
-    // ---- epilogue.  The lane holds, for rows m = m0 + 32 wm + 16 mb + l15, columns 192 wn + 16 nb + 4 g4 + (0..3).
-    float* rs = reinterpret_cast<float*>(lds);                 // [2 passes][2 column halves][128 rows] row sums
-    char* park = lds + 4096;
-    float mean[2], inv[2];
-    // bias + residual (8-byte loads: 4 consecutive columns of the lane's row), row sum
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        const int ml = 32 * wm + 16 * mb + l15;
-        int m = m0 + ml; if (m > M - 1) m = M - 1;
-        float sum = 0.0f;
-#pragma unroll
-        for (int nb = 0; nb < 12; ++nb) {
-            const int n = 192 * wn + 16 * nb + 4 * g4;
-            const float4 bv = *reinterpret_cast<const float4*>(prm + n);
-            const uint2 rv = rres[mb][nb];
-            acc[mb][nb][0] += bv.x + __builtin_bit_cast(float, rv.x << 16);
-            acc[mb][nb][1] += bv.y + __builtin_bit_cast(float, rv.x & 0xFFFF0000u);
-            acc[mb][nb][2] += bv.z + __builtin_bit_cast(float, rv.y << 16);
-            acc[mb][nb][3] += bv.w + __builtin_bit_cast(float, rv.y & 0xFFFF0000u);
-            sum += (acc[mb][nb][0] + acc[mb][nb][1]) + (acc[mb][nb][2] + acc[mb][nb][3]);
-        }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        if (g4 == 0) rs[wn * 128 + ml] = sum;
+    ln_rows_epilogue(lds, prm, acc, rres, out, m0, M, eps, wm, wn, l15, g4);
+}
+
+// ---------------------------------------------------------------- fused FFN: LayerNorm(h + W2 gelu(W1 h + b1) + b2), hidden 384
+// out[M][384] = LayerNorm(h + gelu(h W1^T + b1) W2^T + b2) * gamma + beta   (modeling_bert.py:334-351)
+// The [tokens][1536] intermediate never exists: a workgroup owns 128 rows and walks the
+// intermediate dimension 32 columns at a time.  Per step j ("stage"):
+//   step 1 (wave w, rows 16 w .. 16 w + 15): mid_j = gelu(h W1_j^T + b1_j), 16 x 32 per wave, h fragments
+//           register-resident (48 VGPRs), W1_j fragments from LDS; bf16 into the A buffer (LDS);
+//   step 2 (waves as 4 row groups x 2 column halves, as in gemm_ln_kernel): acc += mid_j W2_j^T.
+// Step 1 runs one stage ahead of step 2.  Both weight blocks are 24 KB, contiguous in HBM (packed at
+// load time; W1 already in its swizzled LDS image), LDS-DMA into rings of three, requested two
+// stages before use.  LDS: 3 x 24 (W2) + 3 x 24 (W1) + 8 (A) + 6 (b1) KB.
+// Against gemm_ws<GELU> + gemm_ln this saves the 2 x 200 MB round trip of the intermediate per 64K
+// tokens and one kernel's prologue/epilogue per row tile.  `out` may alias `h`.
+#define FF_WS (384 * 64)                     // one weight block: 24 KB
+#define FF_W1_OFF (3 * FF_WS)
+#define FF_A_OFF (6 * FF_WS)
+#define FF_B1_OFF (FF_A_OFF + 8192)
+
+// fp32 [I][384] -> bf16 [I / 32][12 k-steps][32 rows][4 chunks of 8], chunk g of row r stored at g ^ ((0 - (r >> 2)) & 3)
+__global__ __launch_bounds__(256) void cvt_pack_w1_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int I)
+{
+    const int64_t total = (int64_t)I * 384;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), gs = (int)((i >> 3) & 3), r = (int)((i >> 5) & 31);
+        const int64_t t = i >> 10;
+        const int sk = (int)(t % 12), j = (int)(t / 12);
+        const int g = gs ^ ((0 - (r >> 2)) & 3);
+        out[i] = f2bf(in[(int64_t)(32 * j + r) * 384 + 32 * sk + 8 * g + e]);
     }
-    __syncthreads();
+}
+
+__global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict__ h, const uint16_t* __restrict__ W1p,
+        const float* __restrict__ b1, const uint16_t* __restrict__ W2p, const float* __restrict__ b2,
+        const float* __restrict__ gamma, const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int I)
+{
+    __shared__ __attribute__((aligned(1024))) char lds[FF_B1_OFF + 1536 * 4];
+    static_assert(FF_B1_OFF + 1536 * 4 <= 160 * 1024, "LDS");
+    static_assert(6 * FF_WS >= 4096 + 128 * LN_TS + 3 * LN_N * 4, "the epilogue's scratch fits in the rings");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = (int)(gridDim.x - 1 - blockIdx.x) * 128;
+    const int nkt = I / 32;                                        // >= 4
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    // b1 -> LDS
+    for (int i = threadIdx.x; i < I / 4; i += 512)
+        *reinterpret_cast<float4*>(lds + FF_B1_OFF + i * 16) = *reinterpret_cast<const float4*>(b1 + 4 * i);
+    // h fragments of the wave's 16 rows (B operand of step 1): lane (l15, g4): row 16 w + l15, k = 32 s + 8 g4 ..
+    bf16x8 hq[12];
+    {
+        int m = m0 + 16 * wave + l15; if (m > M - 1) m = M - 1;
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        const int ml = 32 * wm + 16 * mb + l15;
-        mean[mb] = (rs[ml] + rs[128 + ml]) * (1.0f / LN_N);
-        float sq = 0.0f;
+        for (int sk = 0; sk < 12; ++sk)
+            hq[sk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(h + (int64_t)m * LN_N + 32 * sk + 8 * g4));
+#pragma unroll
+        for (int sk = 0; sk < 12; ++sk) asm volatile("" :: "v"(hq[sk]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- LDS-DMA: per block 24 pieces of 1 KB; wave w issues pieces 3w..3w+2 of each
+    const char* w2src[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int r = 16 * (3 * wave + i) + (lane >> 2);                          // W2 row (output column) 0..383
+        const int ch = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+        w2src[i] = reinterpret_cast<const char*>(W2p) + (int64_t)r * 64 + ch * 16;
+    }
+    const char* w1src = reinterpret_cast<const char*>(W1p) + (3 * wave) * 1024 + lane * 16;
+    auto issue_w2 = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w2src[i] + (int64_t)kt * FF_WS),
+                (lds_ptr_t)(lds + (kt % 3) * FF_WS + (3 * wave + i) * 1024), 16, 0, 0);
+    };
+    auto issue_w1 = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w1src + (int64_t)kt * FF_WS + i * 1024),
+                (lds_ptr_t)(lds + FF_W1_OFF + (kt % 3) * FF_WS + (3 * wave + i) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[2][12];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int nb = 0; nb < 12; ++nb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const float dlt = acc[mb][nb][i] - mean[mb]; sq += dlt * dlt; }
-        sq += __shfl_xor(sq, 16, 64);
-        sq += __shfl_xor(sq, 32, 64);
-        if (g4 == 0) rs[256 + wn * 128 + ml] = sq;
-    }
-    __syncthreads();
+            for (int i = 0; i < 4; ++i) acc[mb][nb][i] = 0.0f;
+
+    const unsigned swz = (unsigned)((0 - (l15 >> 2)) & 3);
+    const unsigned fsw = ((unsigned)g4 ^ swz) << 4;
+    const unsigned a_rd = lds_base + FF_A_OFF + (unsigned)((32 * wm + l15) * 64) + fsw;       // + mb * 1024
+    const unsigned w2_rd = lds_base + (unsigned)((192 * wn + l15) * 64) + fsw;                 // + buf * FF_WS + nb * 1024
+    const unsigned w1_rd = lds_base + FF_W1_OFF + (unsigned)(l15 * 64) + fsw;                  // + buf * FF_WS + s * 2048 + cb * 1024
+    // A write: row 16 w + l15, columns 16 cb + 4 g4 .. + 3 -> chunk 2 cb + (g4 >> 1), half g4 & 1
+    const unsigned a_wr = lds_base + FF_A_OFF + (unsigned)((16 * wave + l15) * 64) + ((((unsigned)g4 >> 1) ^ swz) << 4) + (g4 & 1) * 8;   // cb = 1: ^ 32
+    const unsigned b1_rd = lds_base + FF_B1_OFF + g4 * 16;                                     // + (32 j + 16 cb) * 4
+
+    // ---- step 1 for intermediate block j: the wave's 16 rows x 32 columns
+    auto step1 = [&](int j) __attribute__((always_inline)) {
+        const unsigned wb = w1_rd + (j % 3) * FF_WS;
+        f32x4 a1[2];
+        bf16x8 f[2][4];                                            // two k-steps (x 2 column blocks) in flight
+        auto rd = [&](bf16x8 (&d)[4], int sp) __attribute__((always_inline)) {   // k-steps 2 sp, 2 sp + 1
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                         "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                         : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(wb + sp * 4096));
+        };
+        rd(f[0], 0);
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        const int ml = 32 * wm + 16 * mb + l15;
-        inv[mb] = 1.0f / sqrtf((rs[256 + ml] + rs[384 + ml]) * (1.0f / LN_N) + eps);
-    }
+        for (int sp = 0; sp < 6; ++sp) {
+            if (sp < 5) {
+                rd(f[(sp + 1) & 1], sp + 1);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[sp & 1][0]), "+v"(f[sp & 1][1]), "+v"(f[sp & 1][2]), "+v"(f[sp & 1][3]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[sp & 1][0]), "+v"(f[sp & 1][1]), "+v"(f[sp & 1][2]), "+v"(f[sp & 1][3]));
+            }
 #pragma unroll
-    for (int nb = 0; nb < 12; ++nb) {
-        const int n = 192 * wn + 16 * nb + 4 * g4;
-        const float4 gv = *reinterpret_cast<const float4*>(prm + LN_N + n);
-        const float4 be = *reinterpret_cast<const float4*>(prm + 2 * LN_N + n);
+            for (int q = 0; q < 2; ++q)                            // k-step 2 sp + q: fragments [2 q] (cb 0), [2 q + 1] (cb 1)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            const int ml = 32 * wm + 16 * mb + l15;
-            const float y0 = (acc[mb][nb][0] - mean[mb]) * inv[mb] * gv.x + be.x, y1 = (acc[mb][nb][1] - mean[mb]) * inv[mb] * gv.y + be.y;
-            const float y2 = (acc[mb][nb][2] - mean[mb]) * inv[mb] * gv.z + be.z, y3 = (acc[mb][nb][3] - mean[mb]) * inv[mb] * gv.w + be.w;
-            *reinterpret_cast<uint2*>(park + ml * LN_TS + n * 2) = make_uint2(pack2(y0, y1), pack2(y2, y3));
+                for (int cb = 0; cb < 2; ++cb)
+                    a1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[sp & 1][2 * q + cb], hq[2 * sp + q],
+                                                                     (sp == 0 && q == 0) ? f32x4{} : a1[cb], 0, 0, 0);
         }
-    }
-    __syncthreads();
-    // whole 768-B rows out: thread t takes 16-B chunk t % 48 of rows t / 48 + 10 p (480 of the 512 threads)
-    if (threadIdx.x < 480) {
-        const int r0 = threadIdx.x / 48, ch = threadIdx.x % 48;
-        for (int r = r0; r < 128; r += 10) {
-            const int m = m0 + r;
-            if (m < M) *reinterpret_cast<uint4*>(out + (int64_t)m * LN_N + 8 * ch) = *reinterpret_cast<const uint4*>(park + r * LN_TS + ch * 16);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            float4 bb;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(bb) : "v"(b1_rd + (32 * j + 16 * cb) * 4) : "memory");
+            float v0 = a1[cb][0] + bb.x, v1 = a1[cb][1] + bb.y, v2 = a1[cb][2] + bb.z, v3 = a1[cb][3] + bb.w;
+            gelu_erf4(v0, v1, v2, v3);
+            const uint2 o = make_uint2(pack2(v0, v1), pack2(v2, v3));
+            asm volatile("ds_write_b64 %0, %1" :: "v"(a_wr ^ (cb ? 32u : 0u)), "v"(o) : "memory");
         }
+    };
+
+    // ---- prologue
+    issue_w1(0); issue_w2(0); issue_w1(1); issue_w2(1); issue_w1(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    step1(0);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        // behind this barrier: W2(kt) and W1(kt + 1) have landed for everyone (requested two stages ago),
+        // A(kt) is complete, everyone has left stage kt - 1.  In flight: stage kt - 1's requests (and, early on, the residual).
+        {
+            const int young = (kt >= 1 ? ((kt + 1 < nkt ? 3 : 0) + (kt + 2 < nkt ? 3 : 0)) : 0);
+            if (young == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (young == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) issue_w2(kt + 2);
+        if (kt + 3 < nkt) issue_w1(kt + 3);
+        // the A fragments of this stage, then a second barrier: the A buffer may be overwritten
+        bf16x8 af[2];
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(af[0]), "=&v"(af[1]) : "v"(a_rd) : "memory");
+        __builtin_amdgcn_s_barrier();
+        // step 2: acc += A(kt) W2(kt)^T, 3 groups of 4 W fragments x 2 row blocks
+        {
+            const unsigned wb = w2_rd + (kt % 3) * FF_WS;
+            bf16x8 wf[2][4];
+            auto rdw = [&](bf16x8 (&d)[4], int jg) __attribute__((always_inline)) {
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                             "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                             : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(wb + jg * 4096));
+            };
+            rdw(wf[0], 0);
+#pragma unroll
+            for (int jg = 0; jg < 3; ++jg) {
+                if (jg < 2) {
+                    rdw(wf[(jg + 1) & 1], jg + 1);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[jg & 1][0]), "+v"(wf[jg & 1][1]), "+v"(wf[jg & 1][2]), "+v"(wf[jg & 1][3]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[jg & 1][0]), "+v"(wf[jg & 1][1]), "+v"(wf[jg & 1][2]), "+v"(wf[jg & 1][3]));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+                        acc[mb][4 * jg + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jg & 1][q], af[mb], acc[mb][4 * jg + q], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nkt) step1(kt + 1);
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                               // the rings become the epilogue's scratch
+
+    float* const prm = reinterpret_cast<float*>(lds + 4096 + 128 * LN_TS);
+    if (threadIdx.x < 3 * LN_N / 4) {
+        const int which = threadIdx.x / (LN_N / 4), o = (threadIdx.x % (LN_N / 4)) * 4;
+        const float* srcp = which == 0 ? b2 : which == 1 ? gamma : beta;
+        *reinterpret_cast<float4*>(prm + which * LN_N + o) = *reinterpret_cast<const float4*>(srcp + o);
+    }
+    // the residual is the tile of h the workgroup already holds (hq, step-1 layout): through LDS into the epilogue's layout
+    char* const park = lds + 4096;
+#pragma unroll
+    for (int sk = 0; sk < 12; ++sk)
+        *reinterpret_cast<uint4*>(park + (16 * wave + l15) * LN_TS + (32 * sk + 8 * g4) * 2) = __builtin_bit_cast(uint4, hq[sk]);
+    __syncthreads();
+    uint2 rres[2][12];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb)
+            rres[mb][nb] = *reinterpret_cast<const uint2*>(park + (32 * wm + 16 * mb + l15) * LN_TS + (192 * wn + 16 * nb + 4 * g4) * 2);
+    ln_rows_epilogue(lds, prm, acc, rres, out, m0, M, eps, wm, wn, l15, g4);   // (its park writes come two barriers later)
 }
 
 // ---------------------------------------------------------------- attention (head size 32)
@@ -1060,6 +1278,7 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
 // ================================================================ host side
 struct LayerW {
     uint16_t *Wqkv, *Wo, *Wi, *Wd;                 // bf16 [out][in]
+    uint16_t *Wi_p = nullptr;                      // [I / 32][12][32][32] swizzled LDS image of Wi blocks (ffn_ln_kernel)
     uint16_t *Wo_p = nullptr, *Wd_p = nullptr;     // the same, [in / 32][out][32]: a 32-k stage of gemm_ln_kernel is one contiguous block
     float *bqkv, *bo, *bi, *bd, *g1, *b1, *g2, *b2; // fp32
 };
@@ -1134,7 +1353,7 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
 #define ENC_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { mi_set_error("%s failed: %s", #call, hipGetErrorString(_e)); return fail(_e == hipErrorOutOfMemory ? MI_ERR_OOM : MI_ERR_HIP); } } while (0)
     ENC_HIP(hipMalloc((void**)&e->blob, (size_t)want * sizeof(float)));
     ENC_HIP(hipMemcpyAsync(e->blob, blob_host, (size_t)want * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    const int64_t per_layer_w = (int64_t)4 * H * H + 2 * (int64_t)I * H + ((int64_t)H * H + (int64_t)H * I);   // + packed Wo, Wd
+    const int64_t per_layer_w = (int64_t)4 * H * H + 2 * (int64_t)I * H + ((int64_t)H * H + 2 * (int64_t)H * I);   // + packed Wo, Wd, Wi
     ENC_HIP(hipMalloc((void**)&e->wbf, (size_t)(per_layer_w * cfg->num_hidden_layers) * sizeof(uint16_t)));
     ENC_HIP(hipEventCreate(&e->ev0));
     ENC_HIP(hipEventCreate(&e->ev1));
@@ -1168,6 +1387,7 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
         lw.Wd = w; cvt(Wd, w, (int64_t)H * I); w += (int64_t)H * I;
         lw.Wo_p = w; cvt_pack32_kernel<<<1024, 256, 0, e->stream>>>(Wo, w, H, H); w += (int64_t)H * H;
         lw.Wd_p = w; cvt_pack32_kernel<<<1024, 256, 0, e->stream>>>(Wd, w, H, I); w += (int64_t)H * I;
+        lw.Wi_p = w; if (H == 384) cvt_pack_w1_kernel<<<1024, 256, 0, e->stream>>>(Wi, w, I); w += (int64_t)H * I;
         // fused qkv bias: bq|bk|bv are not contiguous in the blob -> a small packed copy
         ENC_HIP(hipMalloc((void**)&lw.bqkv, (size_t)3 * H * sizeof(float)));
         ENC_HIP(hipMemcpyAsync(lw.bqkv, bq, (size_t)H * 4, hipMemcpyDeviceToDevice, e->stream));
@@ -1274,6 +1494,8 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
     // hidden size 384: the two N = 384 projections run fused with their LayerNorm (MI_GEMM_LN=0: separate kernels)
     static const bool ln_off = getenv("MI_GEMM_LN") && atoi(getenv("MI_GEMM_LN")) == 0;
     const bool fused_ln = !ln_off && H == LN_N && I % 64 == 0;
+    static const bool ffn_off = getenv("MI_FFN_FUSED") && atoi(getenv("MI_FFN_FUSED")) == 0;
+    const bool fused_ffn = fused_ln && !ffn_off && I == 1536;
     MI_HIP(hipEventRecord(e->ev0, st));
     if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
@@ -1286,6 +1508,10 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
             launch_gemm<EPI_RESID>(st, ctx, lw.Wo, lw.bo, h, tmp, (int)T, H, H);
             if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
             else add_ln_kernel<2><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
+        }
+        if (fused_ffn) {
+            ffn_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I);
+            continue;
         }
         const bool mid_blocked = launch_gemm<EPI_GELU>(st, h, lw.Wi, lw.bi, nullptr, mid, (int)T, I, H, fused_ln);
         if (fused_ln) {
