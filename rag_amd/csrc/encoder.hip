@@ -903,54 +903,61 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
     const unsigned w1_rd = lds_base + FF_W1_OFF + (unsigned)(l15 * 64) + fsw;                  // + buf * FF_WS + s * 2048 + cb * 1024
     // A write: row 16 w + l15, columns 16 cb + 4 g4 .. + 3 -> chunk 2 cb + (g4 >> 1), half g4 & 1
     const unsigned a_wr = lds_base + FF_A_OFF + (unsigned)((16 * wave + l15) * 64) + ((((unsigned)g4 >> 1) ^ swz) << 4) + (g4 & 1) * 8;   // cb = 1: ^ 32
-    const unsigned b1_rd = lds_base + FF_B1_OFF + g4 * 16;                                     // + (32 j + 16 cb) * 4
 
-    // ---- step 1 for intermediate block j: the wave's 16 rows x 32 columns
-    auto step1 = [&](int j) __attribute__((always_inline)) {
-        const unsigned wb = w1_rd + (j % 3) * FF_WS;
-        f32x4 a1[2];
-        bf16x8 f[2][4];                                            // two k-steps (x 2 column blocks) in flight
-        auto rd = [&](bf16x8 (&d)[4], int sp) __attribute__((always_inline)) {   // k-steps 2 sp, 2 sp + 1
-            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
-                         "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
-                         : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(wb + sp * 4096));
-        };
-        rd(f[0], 0);
+    // One fragment group = 4 ds_read_b128 (read one group ahead of its MFMAs, across the step boundary):
+    //   groups 0..2: step 2 of stage kt (W2 fragments of column blocks 4 g .. 4 g + 3, 8 MFMAs each);
+    //   groups 3..8: step 1 of stage kt + 1 (W1 fragments of k-steps 2 sp, 2 sp + 1 x 2 column blocks, 4 MFMAs each).
+    bf16x8 fr[2][4];
+    auto rd_group = [&](bf16x8 (&d)[4], unsigned base) __attribute__((always_inline)) {
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                     "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(base));
+    };
+    auto wait4 = [&](bf16x8 (&d)[4]) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+    };
+    auto wait0 = [&](bf16x8 (&d)[4]) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+    };
+    f32x4 a1[2];
+    auto step1_mma = [&](bf16x8 (&d)[4], int sp) __attribute__((always_inline)) {
 #pragma unroll
-        for (int sp = 0; sp < 6; ++sp) {
-            if (sp < 5) {
-                rd(f[(sp + 1) & 1], sp + 1);
-                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[sp & 1][0]), "+v"(f[sp & 1][1]), "+v"(f[sp & 1][2]), "+v"(f[sp & 1][3]));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[sp & 1][0]), "+v"(f[sp & 1][1]), "+v"(f[sp & 1][2]), "+v"(f[sp & 1][3]));
-            }
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int q = 0; q < 2; ++q)                            // k-step 2 sp + q: fragments [2 q] (cb 0), [2 q + 1] (cb 1)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-                    a1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[sp & 1][2 * q + cb], hq[2 * sp + q],
-                                                                     (sp == 0 && q == 0) ? f32x4{} : a1[cb], 0, 0, 0);
-        }
+            for (int cb = 0; cb < 2; ++cb)
+                a1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d[2 * q + cb], hq[2 * sp + q], (sp == 0 && q == 0) ? f32x4{} : a1[cb], 0, 0, 0);
+    };
+    auto step1_finish = [&](const float4 (&bb)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            float4 bb;
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(bb) : "v"(b1_rd + (32 * j + 16 * cb) * 4) : "memory");
-            float v0 = a1[cb][0] + bb.x, v1 = a1[cb][1] + bb.y, v2 = a1[cb][2] + bb.z, v3 = a1[cb][3] + bb.w;
+            float v0 = a1[cb][0] + bb[cb].x, v1 = a1[cb][1] + bb[cb].y, v2 = a1[cb][2] + bb[cb].z, v3 = a1[cb][3] + bb[cb].w;
             gelu_erf4(v0, v1, v2, v3);
             const uint2 o = make_uint2(pack2(v0, v1), pack2(v2, v3));
             asm volatile("ds_write_b64 %0, %1" :: "v"(a_wr ^ (cb ? 32u : 0u)), "v"(o) : "memory");
         }
     };
 
-    // ---- prologue
+    // ---- prologue: W1(0..2), W2(0..1) in flight, A(0) computed
     issue_w1(0); issue_w2(0); issue_w1(1); issue_w2(1); issue_w1(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    step1(0);
+    {
+        float4 bb[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) bb[cb] = *reinterpret_cast<const float4*>(lds + FF_B1_OFF + (16 * cb + 4 * g4) * 4);
+        rd_group(fr[0], w1_rd);
+        static_for<6>([&](auto SPc) __attribute__((always_inline)) {
+            constexpr int sp = decltype(SPc)::value;
+            if constexpr (sp < 5) { rd_group(fr[(sp + 1) & 1], w1_rd + (sp + 1) * 4096); wait4(fr[sp & 1]); }
+            else wait0(fr[sp & 1]);
+            step1_mma(fr[sp & 1], sp);
+        });
+        step1_finish(bb);
+    }
 
     for (int kt = 0; kt < nkt; ++kt) {
         // behind this barrier: W2(kt) and W1(kt + 1) have landed for everyone (requested two stages ago),
-        // A(kt) is complete, everyone has left stage kt - 1.  In flight: stage kt - 1's requests (and, early on, the residual).
+        // A(kt) is complete, everyone has left stage kt - 1.  In flight: stage kt - 1's requests.
         {
             const int young = (kt >= 1 ? ((kt + 1 < nkt ? 3 : 0) + (kt + 2 < nkt ? 3 : 0)) : 0);
             if (young == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -959,39 +966,50 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nkt) issue_w2(kt + 2);
-        if (kt + 3 < nkt) issue_w1(kt + 3);
-        // the A fragments of this stage, then a second barrier: the A buffer may be overwritten
+        const bool more = kt + 1 < nkt;                            // step 1 of the next stage follows
+        const unsigned w2b = w2_rd + (kt % 3) * FF_WS, w1b = w1_rd + ((kt + 1) % 3) * FF_WS;
+        // the A fragments and the first W2 group, then a second barrier: the A buffer may be overwritten
         bf16x8 af[2];
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(af[0]), "=&v"(af[1]) : "v"(a_rd) : "memory");
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(af[0]), "=&v"(af[1]) : "v"(a_rd));
+        rd_group(fr[0], w2b);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0]), "+v"(af[1]));
         __builtin_amdgcn_s_barrier();
-        // step 2: acc += A(kt) W2(kt)^T, 3 groups of 4 W fragments x 2 row blocks
-        {
-            const unsigned wb = w2_rd + (kt % 3) * FF_WS;
-            bf16x8 wf[2][4];
-            auto rdw = [&](bf16x8 (&d)[4], int jg) __attribute__((always_inline)) {
-                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
-                             "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
-                             : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(wb + jg * 4096));
-            };
-            rdw(wf[0], 0);
+        // (plain loads: hipcc places its own wait before their use at the end of the stage)
+        float4 bb[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+        if (more) {
 #pragma unroll
-            for (int jg = 0; jg < 3; ++jg) {
-                if (jg < 2) {
-                    rdw(wf[(jg + 1) & 1], jg + 1);
-                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[jg & 1][0]), "+v"(wf[jg & 1][1]), "+v"(wf[jg & 1][2]), "+v"(wf[jg & 1][3]));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[jg & 1][0]), "+v"(wf[jg & 1][1]), "+v"(wf[jg & 1][2]), "+v"(wf[jg & 1][3]));
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int mb = 0; mb < 2; ++mb)
-                        acc[mb][4 * jg + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jg & 1][q], af[mb], acc[mb][4 * jg + q], 0, 0, 0);
-            }
+            for (int cb = 0; cb < 2; ++cb) bb[cb] = *reinterpret_cast<const float4*>(lds + FF_B1_OFF + (32 * (kt + 1) + 16 * cb + 4 * g4) * 4);
         }
-        if (kt + 1 < nkt) step1(kt + 1);
+        static_for<9>([&](auto Gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(Gc)::value;
+            if (g < 3 || more) {
+                // read the next group, wait for this one
+                if constexpr (g < 2) { rd_group(fr[(g + 1) & 1], w2b + (g + 1) * 4096); wait4(fr[g & 1]); }
+                else if constexpr (g == 2) { if (more) { rd_group(fr[1], w1b); wait4(fr[0]); } else wait0(fr[0]); }
+                else if constexpr (g < 8) { rd_group(fr[(g + 1) & 1], w1b + (g - 2) * 4096); wait4(fr[g & 1]); }
+                else wait0(fr[g & 1]);
+                if constexpr (g < 3) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb)
+                            acc[mb][4 * g + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g & 1][q], af[mb], acc[mb][4 * g + q], 0, 0, 0);
+                } else {
+                    step1_mma(fr[g & 1], g - 3);
+                }
+            }
+            // one DMA request behind each of the first six groups (50 cycles each: in the MFMAs' shadow, not ahead of them)
+            if constexpr (g < 3) {
+                if (kt + 2 < nkt)
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w2src[g] + (int64_t)(kt + 2) * FF_WS),
+                        (lds_ptr_t)(lds + ((kt + 2) % 3) * FF_WS + (3 * wave + g) * 1024), 16, 0, 0);
+            } else if constexpr (g < 6) {
+                if (kt + 3 < nkt)
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w1src + (int64_t)(kt + 3) * FF_WS + (g - 3) * 1024),
+                        (lds_ptr_t)(lds + FF_W1_OFF + ((kt + 3) % 3) * FF_WS + (3 * wave + (g - 3)) * 1024), 16, 0, 0);
+            }
+        });
+        if (more) step1_finish(bb);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                               // the rings become the epilogue's scratch
