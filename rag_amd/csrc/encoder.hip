@@ -813,8 +813,8 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
 //   step 1 (wave w, rows 16 w .. 16 w + 15): mid_j = gelu(h W1_j^T + b1_j), 16 x 32 per wave, h fragments
 //           register-resident (48 VGPRs), W1_j fragments from LDS; bf16 into the A buffer (LDS);
 //   step 2 (waves as 4 row groups x 2 column halves, as in gemm_ln_kernel): acc += mid_j W2_j^T.
-// Step 1 runs one stage ahead of step 2.  Both weight blocks are 24 KB, contiguous in HBM (packed at
-// load time; W1 already in its swizzled LDS image), LDS-DMA into rings of three, requested two
+// Step 1 runs two stages ahead of step 2, its GELU one.  Both weight blocks are 24 KB, contiguous in HBM
+// (packed at load time; W1 already in its swizzled LDS image), LDS-DMA into rings of three, requested two
 // stages before use.  LDS: 3 x 24 (W2) + 3 x 24 (W1) + 8 (A) + 6 (b1) KB.
 // Against gemm_ws<GELU> + gemm_ln this saves the 2 x 200 MB round trip of the intermediate per 64K
 // tokens and one kernel's prologue/epilogue per row tile.  `out` may alias `h`.
@@ -919,73 +919,85 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
     auto wait0 = [&](bf16x8 (&d)[4]) __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
     };
-    f32x4 a1[2];
+    // Step 1 runs TWO stages ahead of step 2 and its bias + GELU + store ("finish") one stage later, split in
+    // two halves behind the first two MFMA groups of step 2: 8 values per lane are a long dependent
+    // chain with no parallelism of their own (~500 cycles exposed when they stood at the end of the
+    // stage); behind the MFMAs they cost issue slots only.
+    f32x4 a1n[2], a1p[2];                                          // block being accumulated / block waiting for its finish
     auto step1_mma = [&](bf16x8 (&d)[4], int sp) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
-                a1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d[2 * q + cb], hq[2 * sp + q], (sp == 0 && q == 0) ? f32x4{} : a1[cb], 0, 0, 0);
+                a1n[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d[2 * q + cb], hq[2 * sp + q], (sp == 0 && q == 0) ? f32x4{} : a1n[cb], 0, 0, 0);
     };
-    auto step1_finish = [&](const float4 (&bb)[2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            float v0 = a1[cb][0] + bb[cb].x, v1 = a1[cb][1] + bb[cb].y, v2 = a1[cb][2] + bb[cb].z, v3 = a1[cb][3] + bb[cb].w;
-            gelu_erf4(v0, v1, v2, v3);
-            const uint2 o = make_uint2(pack2(v0, v1), pack2(v2, v3));
-            asm volatile("ds_write_b64 %0, %1" :: "v"(a_wr ^ (cb ? 32u : 0u)), "v"(o) : "memory");
-        }
+    auto finish_half = [&](int cb, const float4& bb) __attribute__((always_inline)) {
+        float v0 = a1p[cb][0] + bb.x, v1 = a1p[cb][1] + bb.y, v2 = a1p[cb][2] + bb.z, v3 = a1p[cb][3] + bb.w;
+        gelu_erf4(v0, v1, v2, v3);
+        const uint2 o = make_uint2(pack2(v0, v1), pack2(v2, v3));
+        asm volatile("ds_write_b64 %0, %1" :: "v"(a_wr ^ (cb ? 32u : 0u)), "v"(o) : "memory");
+    };
+    auto step1_all = [&](int j) __attribute__((always_inline)) {                // prologue only: no overlap
+        const unsigned wb = w1_rd + (j % 3) * FF_WS;
+        rd_group(fr[0], wb);
+        static_for<6>([&](auto SPc) __attribute__((always_inline)) {
+            constexpr int sp = decltype(SPc)::value;
+            if constexpr (sp < 5) { rd_group(fr[(sp + 1) & 1], wb + (sp + 1) * 4096); wait4(fr[sp & 1]); }
+            else wait0(fr[sp & 1]);
+            step1_mma(fr[sp & 1], sp);
+        });
     };
 
-    // ---- prologue: W1(0..2), W2(0..1) in flight, A(0) computed
-    issue_w1(0); issue_w2(0); issue_w1(1); issue_w2(1); issue_w1(2);
+    // ---- prologue: A(0) computed, block 1 accumulated, W1(2), W1(3), W2(0), W2(1) landed / in flight
+    issue_w1(0); issue_w1(1); issue_w1(2); issue_w2(0); issue_w2(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
         float4 bb[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) bb[cb] = *reinterpret_cast<const float4*>(lds + FF_B1_OFF + (16 * cb + 4 * g4) * 4);
-        rd_group(fr[0], w1_rd);
-        static_for<6>([&](auto SPc) __attribute__((always_inline)) {
-            constexpr int sp = decltype(SPc)::value;
-            if constexpr (sp < 5) { rd_group(fr[(sp + 1) & 1], w1_rd + (sp + 1) * 4096); wait4(fr[sp & 1]); }
-            else wait0(fr[sp & 1]);
-            step1_mma(fr[sp & 1], sp);
-        });
-        step1_finish(bb);
+        step1_all(0);
+        a1p[0] = a1n[0]; a1p[1] = a1n[1];
+        finish_half(0, bb[0]); finish_half(1, bb[1]);
+        step1_all(1);
+        a1p[0] = a1n[0]; a1p[1] = a1n[1];
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // everyone has left W1(0): its buffer takes W1(3)
+    if (3 < nkt) issue_w1(3);
 
     for (int kt = 0; kt < nkt; ++kt) {
-        // behind this barrier: W2(kt) and W1(kt + 1) have landed for everyone (requested two stages ago),
+        // behind this barrier: W2(kt) and W1(kt + 2) have landed for everyone (requested two stages ago),
         // A(kt) is complete, everyone has left stage kt - 1.  In flight: stage kt - 1's requests.
         {
-            const int young = (kt >= 1 ? ((kt + 1 < nkt ? 3 : 0) + (kt + 2 < nkt ? 3 : 0)) : 0);
+            const int young = (kt >= 1) ? ((kt + 1 < nkt ? 3 : 0) + (kt + 3 < nkt ? 3 : 0)) : (3 < nkt ? 3 : 0);
             if (young == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if (young == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const bool more = kt + 1 < nkt;                            // step 1 of the next stage follows
-        const unsigned w2b = w2_rd + (kt % 3) * FF_WS, w1b = w1_rd + ((kt + 1) % 3) * FF_WS;
+        const bool more1 = kt + 1 < nkt;                           // A(kt + 1) is still to be written (finish of block kt + 1)
+        const bool more2 = kt + 2 < nkt;                           // step 1 of block kt + 2 follows
+        const unsigned w2b = w2_rd + (kt % 3) * FF_WS, w1b = w1_rd + ((kt + 2) % 3) * FF_WS;
+        // (plain loads: hipcc places its own wait before their use)
+        float4 bb[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+        if (more1) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) bb[cb] = *reinterpret_cast<const float4*>(lds + FF_B1_OFF + (32 * (kt + 1) + 16 * cb + 4 * g4) * 4);
+        }
         // the A fragments and the first W2 group, then a second barrier: the A buffer may be overwritten
         bf16x8 af[2];
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(af[0]), "=&v"(af[1]) : "v"(a_rd));
         rd_group(fr[0], w2b);
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0]), "+v"(af[1]));
         __builtin_amdgcn_s_barrier();
-        // (plain loads: hipcc places its own wait before their use at the end of the stage)
-        float4 bb[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-        if (more) {
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) bb[cb] = *reinterpret_cast<const float4*>(lds + FF_B1_OFF + (32 * (kt + 1) + 16 * cb + 4 * g4) * 4);
-        }
         static_for<9>([&](auto Gc) __attribute__((always_inline)) {
             constexpr int g = decltype(Gc)::value;
-            if (g < 3 || more) {
+            if (g < 3 || more2) {
                 // read the next group, wait for this one
                 if constexpr (g < 2) { rd_group(fr[(g + 1) & 1], w2b + (g + 1) * 4096); wait4(fr[g & 1]); }
-                else if constexpr (g == 2) { if (more) { rd_group(fr[1], w1b); wait4(fr[0]); } else wait0(fr[0]); }
+                else if constexpr (g == 2) { if (more2) { rd_group(fr[1], w1b); wait4(fr[0]); } else wait0(fr[0]); }
                 else if constexpr (g < 8) { rd_group(fr[(g + 1) & 1], w1b + (g - 2) * 4096); wait4(fr[g & 1]); }
                 else wait0(fr[g & 1]);
                 if constexpr (g < 3) {
@@ -1004,12 +1016,14 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
                     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w2src[g] + (int64_t)(kt + 2) * FF_WS),
                         (lds_ptr_t)(lds + ((kt + 2) % 3) * FF_WS + (3 * wave + g) * 1024), 16, 0, 0);
             } else if constexpr (g < 6) {
-                if (kt + 3 < nkt)
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w1src + (int64_t)(kt + 3) * FF_WS + (g - 3) * 1024),
-                        (lds_ptr_t)(lds + FF_W1_OFF + ((kt + 3) % 3) * FF_WS + (3 * wave + (g - 3)) * 1024), 16, 0, 0);
+                if (kt + 4 < nkt)
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w1src + (int64_t)(kt + 4) * FF_WS + (g - 3) * 1024),
+                        (lds_ptr_t)(lds + FF_W1_OFF + ((kt + 4) % 3) * FF_WS + (3 * wave + (g - 3)) * 1024), 16, 0, 0);
             }
+            // the finish of block kt + 1, half behind each of the first two MFMA groups
+            if constexpr (g < 2) { if (more1) finish_half(g, bb[g]); }
         });
-        if (more) step1_finish(bb);
+        if (more2) { a1p[0] = a1n[0]; a1p[1] = a1n[1]; }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                               // the rings become the epilogue's scratch
