@@ -141,3 +141,44 @@ def test_hidden_768_takes_the_general_kernels(oracle_mod):
     E = Encoder(cfg, blob).encode_ids(ids, mask)
     Eo = oracle_mod.encode(ocfg, blob, ids, mask)
     assert np.all(_cos_err(E, Eo) < TOL), _cos_err(E, Eo)
+
+
+_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import oracle
+from rag_amd._capi import BertConfig
+from rag_amd.embeddings import Encoder
+from rag_amd.encoder_weights import random_blob
+vals = (2000, 384, 2, 12, 1536, 512, 2, 1e-12, 1)
+cfg, ocfg = BertConfig(*vals), oracle.BertConfig(*vals)
+blob = random_blob(cfg, seed=3, init_range=0.05)
+rng = np.random.default_rng(4)
+worst = 0.0
+for B, L in ((131, 200), (5, 100)):                      # 26200 tokens (weight-stationary GEMMs apply) and a small batch
+    ids = rng.integers(0, 2000, size=(B, L)).astype(np.int32)
+    mask = np.ones((B, L), dtype=np.int32)
+    mask[1, L // 3:] = 0
+    E = Encoder(cfg, blob).encode_ids(ids, mask)
+    sel = [0, 1, B - 1]
+    Eo = oracle.encode(ocfg, blob, ids[sel], mask[sel])
+    cos = (E[sel] * Eo).sum(1) / (np.linalg.norm(E[sel], axis=1) * np.linalg.norm(Eo, axis=1))
+    worst = max(worst, float((1.0 - cos).max()))
+print("WORST", worst)
+"""
+
+
+@pytest.mark.parametrize("env", [{"MI_FFN_FUSED": "0"}, {"MI_FFN_FUSED": "0", "MI_GEMM_WS": "0"},
+                                 {"MI_FFN_FUSED": "0", "MI_GEMM_LN": "0"}])
+def test_unfused_kernel_paths_in_a_child_process(env):
+    """The kernels the fused ones replaced stay in the library as fallbacks (other shapes, switches read once per
+    process): each combination runs in its own process and is held to the same bar."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", _CHILD % root], env=e, capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0, out.stderr[-2000:]
+    worst = float(out.stdout.strip().split("WORST")[-1])
+    assert worst < TOL, (env, worst)
