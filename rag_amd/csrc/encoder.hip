@@ -575,6 +575,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
 // ---- shared epilogue of the row-complete kernels: bias + residual, LayerNorm over the 384 columns, bf16 rows out.
 // The lane holds, for rows m = m0 + 32 wm + 16 mb + l15, columns 192 wn + 16 nb + 4 g4 + (0..3).
 // lds: >= 4096 + 128 * LN_TS bytes of scratch nobody else touches any more; prm: bias | gamma | beta (fp32, LDS).
+template <bool STORE = true>
 __device__ __forceinline__ void ln_rows_epilogue(char* lds, const float* prm, f32x4 (&acc)[2][12], const uint2 (&rres)[2][12],
         uint16_t* __restrict__ out, int m0, int M, float eps, int wm, int wn, int l15, int g4)
 {
@@ -635,6 +636,7 @@ __device__ __forceinline__ void ln_rows_epilogue(char* lds, const float* prm, f3
         }
     }
     __syncthreads();
+    if constexpr (!STORE) return;                              // the caller goes on with the parked tile (lds + 4096, rows of LN_TS bytes)
     // whole 768-B rows out: thread t takes 16-B chunk t % 48 of rows t / 48 + 10 p (480 of the 512 threads)
     if (threadIdx.x < 480) {
         const int r0 = threadIdx.x / 48, ch = threadIdx.x % 48;
@@ -659,19 +661,16 @@ __device__ __forceinline__ void ln_rows_epilogue(char* lds, const float* prm, f3
 // `out` may alias `resid`: a workgroup reads and writes only its own rows.
 #define LN_STAGE (512 * 64)                  // 128 A rows + 384 W rows, 64 B (32 k) each
 
-__global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+// The main loop of the row-complete GEMM: acc = A[m0 .. m0 + 127][K] * W^T for all 384 columns, the residual rows
+// requested on the way (rres), bias / gamma / beta copied to LDS behind the ring.  Ends with a workgroup
+// barrier: the ring is free.  Shared by gemm_ln_kernel and the front phase of ffn_ln_kernel.
+__device__ __forceinline__ void rowgemm384_mainloop(char* lds, const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         const float* __restrict__ bias, const uint16_t* __restrict__ resid, const float* __restrict__ gamma,
-        const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int K, int a_blocked)
+        const float* __restrict__ beta, int M, int K, int a_blocked, int m0, int lane, int wave,
+        f32x4 (&acc)[2][12], uint2 (&rres)[2][12])
 {
-    __shared__ __attribute__((aligned(1024))) char lds[4 * LN_STAGE + 3 * LN_N * 4];   // ring | bias, gamma, beta (fp32)
-    static_assert(4 * LN_STAGE >= 4096 + 128 * LN_TS, "the epilogue parks the tile in the ring");
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, g4 = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    // last rows first: the producer kernel wrote them last, so they are the part of A still in the Infinity Cache
-    const int m0 = (int)(gridDim.x - 1 - blockIdx.x) * 128;
-
     // LDS-DMA.  A stage is 32 k: 512 rows (128 A + 384 W) x 64 B = 32 KB, ring of four.  (The first form
     // had two 64-KB stages: the next stage could only be requested one stage ahead, and a stage took
     // 2.6 us against 0.75 us of MFMA -- the L2 -> LDS latency, not the arithmetic, set the pace.)
@@ -689,7 +688,6 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
     }
     // The residual rows (8 bytes per lane per accumulator block) are requested during the first
     // stage and sit in registers until the epilogue: fetched there they cost ~5 us per tile.
-    uint2 rres[2][12];
     auto prefetch_resid = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
@@ -724,7 +722,6 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
                 (lds_ptr_t)(lds + (kt & 3) * LN_STAGE + (4 * wave + i) * 1024), 16, 0, 0);
     };
 
-    f32x4 acc[2][12];                                  // [16-row block][16-column block]
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -803,6 +800,26 @@ __global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict
     }
     __syncthreads();                                               // the ring becomes the epilogue's scratch
 
+}
+
+
+__global__ __launch_bounds__(512) void gemm_ln_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+        const float* __restrict__ bias, const uint16_t* __restrict__ resid, const float* __restrict__ gamma,
+        const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int K, int a_blocked)
+{
+    __shared__ __attribute__((aligned(1024))) char lds[4 * LN_STAGE + 3 * LN_N * 4];   // ring | bias, gamma, beta (fp32)
+    static_assert(4 * LN_STAGE >= 4096 + 128 * LN_TS, "the epilogue parks the tile in the ring");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    // last rows first: the producer kernel wrote them last, so they are the part of A still in the Infinity Cache
+    const int m0 = (int)(gridDim.x - 1 - blockIdx.x) * 128;
+
+    f32x4 acc[2][12];                                  // [16-row block][16-column block]
+    uint2 rres[2][12];
+    rowgemm384_mainloop(lds, A, W, bias, resid, gamma, beta, M, K, a_blocked, m0, lane, wave, acc, rres);
+    const float* const prm = reinterpret_cast<const float*>(lds + 4 * LN_STAGE);
     ln_rows_epilogue(lds, prm, acc, rres, out, m0, M, eps, wm, wn, l15, g4);
 }
 
@@ -836,9 +853,15 @@ __global__ __launch_bounds__(256) void cvt_pack_w1_kernel(const float* __restric
     }
 }
 
+// FRONT: the attention output projection + residual + LayerNorm (what gemm_ln_kernel does for K = 384) runs first, on the
+// same 128 rows: h is then the layer's input (the residual of that LayerNorm), its result never goes to HBM -- it is
+// parked in LDS, becomes the h fragments of step 1 and the residual of the final LayerNorm.
+template <bool FRONT>
 __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict__ h, const uint16_t* __restrict__ W1p,
         const float* __restrict__ b1, const uint16_t* __restrict__ W2p, const float* __restrict__ b2,
-        const float* __restrict__ gamma, const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int I)
+        const float* __restrict__ gamma, const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int I,
+        const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ Wo_p, const float* __restrict__ bo,
+        const float* __restrict__ gamma1, const float* __restrict__ beta1)
 {
     __shared__ __attribute__((aligned(1024))) char lds[FF_B1_OFF + 1536 * 4];
     static_assert(FF_B1_OFF + 1536 * 4 <= 160 * 1024, "LDS");
@@ -854,9 +877,21 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
     // b1 -> LDS
     for (int i = threadIdx.x; i < I / 4; i += 512)
         *reinterpret_cast<float4*>(lds + FF_B1_OFF + i * 16) = *reinterpret_cast<const float4*>(b1 + 4 * i);
+    f32x4 acc[2][12];
     // h fragments of the wave's 16 rows (B operand of step 1): lane (l15, g4): row 16 w + l15, k = 32 s + 8 g4 ..
     bf16x8 hq[12];
-    {
+    if constexpr (FRONT) {
+        static_assert(FF_B1_OFF >= 4 * LN_STAGE + 3 * LN_N * 4, "b1 sits behind the front phase's ring and parameters");
+        uint2 rres[2][12];
+        rowgemm384_mainloop(lds, ctx, Wo_p, bo, h, gamma1, beta1, M, LN_N, 1, m0, lane, wave, acc, rres);
+        ln_rows_epilogue<false>(lds, reinterpret_cast<const float*>(lds + 4 * LN_STAGE), acc, rres, nullptr, m0, M, eps, wm, wn, l15, g4);
+#pragma unroll
+        for (int sk = 0; sk < 12; ++sk)
+            hq[sk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + 4096 + (16 * wave + l15) * LN_TS + (32 * sk + 8 * g4) * 2));
+#pragma unroll
+        for (int sk = 0; sk < 12; ++sk) asm volatile("" :: "v"(hq[sk]));
+        __syncthreads();                                           // the parked tile gives way to the weight rings
+    } else {
         int m = m0 + 16 * wave + l15; if (m > M - 1) m = M - 1;
 #pragma unroll
         for (int sk = 0; sk < 12; ++sk)
@@ -888,7 +923,6 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
                 (lds_ptr_t)(lds + FF_W1_OFF + (kt % 3) * FF_WS + (3 * wave + i) * 1024), 16, 0, 0);
     };
 
-    f32x4 acc[2][12];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -1528,12 +1562,20 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
     const bool fused_ln = !ln_off && H == LN_N && I % 64 == 0;
     static const bool ffn_off = getenv("MI_FFN_FUSED") && atoi(getenv("MI_FFN_FUSED")) == 0;
     const bool fused_ffn = fused_ln && !ffn_off && I == 1536;
+    static const bool front_off = getenv("MI_FFN_FRONT") && atoi(getenv("MI_FFN_FRONT")) == 0;
+    const bool fused_front = fused_ffn && !front_off;
     MI_HIP(hipEventRecord(e->ev0, st));
     if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     for (const LayerW& lw : e->layers) {
         const bool qkv_blocked = launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H, true);
         attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, scale_log2e, qkv_blocked ? 1 : 0, fused_ln ? 1 : 0);
+        if (fused_front) {
+            // attention output projection + LayerNorm + FFN + LayerNorm in one kernel per 128-row tile
+            ffn_ln_kernel<true><<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I,
+                                                                             ctx, lw.Wo_p, lw.bo, lw.g1, lw.b1);
+            continue;
+        }
         if (fused_ln) {
             gemm_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(ctx, lw.Wo_p, lw.bo, h, lw.g1, lw.b1, c.layer_norm_eps, h, (int)T, H, 1);
         } else {
@@ -1542,7 +1584,8 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
             else add_ln_kernel<2><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
         }
         if (fused_ffn) {
-            ffn_ln_kernel<<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I);
+            ffn_ln_kernel<false><<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I,
+                                                                              nullptr, nullptr, nullptr, nullptr, nullptr);
             continue;
         }
         const bool mid_blocked = launch_gemm<EPI_GELU>(st, h, lw.Wi, lw.bi, nullptr, mid, (int)T, I, H, fused_ln);
