@@ -1538,7 +1538,11 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
     MI_REQUIRE(T < ((int64_t)1 << 31) / 16, "encode: too many tokens in one call (%lld)", (long long)T);
     // workspace: h, tmp, ctx [T][H]; qkv [T][3H]; mid [T][I]  (bf16)
     // + 128 rows of slack: the weight-stationary GEMM streams whole 128-row tiles of its A operand
-    const size_t need = ((size_t)T * ((size_t)3 * H + 3 * H + I) + (size_t)128 * I) * sizeof(uint16_t);
+    // ctx, qkv and mid may be written in the blocked [rows / 128][cols / 32][128][32] layout, which covers whole
+    // 128-row tiles: each of them gets roundup(T, 128) rows, so a tile of one buffer never reaches into the next
+    // (the attention kernel writes ctx while other workgroups still read qkv).
+    const size_t Tp = ((size_t)T + 127) / 128 * 128;
+    const size_t need = ((size_t)T * 2 * H + Tp * ((size_t)H + 3 * H + I) + (size_t)128 * I) * sizeof(uint16_t);
     if (need > e->ws_bytes) {
         if (e->ws) { MI_HIP(hipStreamSynchronize(st)); (void)hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0; }
         hipError_t er = hipMalloc(&e->ws, need);
@@ -1548,8 +1552,8 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
     uint16_t* h = (uint16_t*)e->ws;
     uint16_t* tmp = h + (size_t)T * H;
     uint16_t* ctx = tmp + (size_t)T * H;
-    uint16_t* qkv = ctx + (size_t)T * H;
-    uint16_t* mid = qkv + (size_t)T * 3 * H;
+    uint16_t* qkv = ctx + Tp * H;
+    uint16_t* mid = qkv + Tp * 3 * H;
 
     const unsigned tok_grid = (unsigned)((T + 3) / 4);
     const int Lp = (L + 31) / 32 * 32;
