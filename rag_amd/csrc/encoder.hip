@@ -4,19 +4,26 @@
 // retriever :296), i.e. sentence-transformers -> transformers BertModel (modeling_bert.py):
 //
 //   embed_ln_kernel   word + token_type(0) + position, LayerNorm            (:98-107)
-//   gemm_bf16_kernel  x W^T + b on bf16 MFMA (32x32x16), fp32 accumulate, fused epilogues:
-//                     QKV (bias), FFN1 (bias + erf-GELU), out-proj / FFN2 (bias + residual)
-//                                                                          (:175-177, :289-293, :334-351)
+//   gemm_ws_kernel    QKV projection (bias), weight-stationary: W fragments in registers, the
+//                     activations streamed once through LDS; also FFN1 (bias + erf-GELU) in the
+//                     unfused form                                         (:175-177, :334-337)
 //   attn_kernel       softmax(Q K^T dh^-1/2 + mask) V per (sequence, head): swapped-QK^T MFMA
 //                     so each lane owns one query's scores, online softmax in registers, the
 //                     P tile re-used as the next MFMA's B operand without leaving registers
 //                                                                          (:111-136)
-//   add_ln_kernel     LayerNorm of (dense output + residual), fp32 statistics, eps 1e-12
+//   ffn_ln_kernel     per 128-row tile: [attention output projection + residual + LayerNorm]
+//                     -> FFN1 + erf-GELU -> FFN2 + residual + LayerNorm; neither the
+//                     post-attention hidden state nor the 1536-wide intermediate leaves the CU
+//                                                                          (:289-293, :334-351)
+//   gemm_ln_kernel    one row-complete GEMM + residual + LayerNorm (the pieces of the above, unfused)
+//   gemm_bf16_kernel  x W^T + b on 128x128 tiles with fused epilogues: the general form
+//                     (other hidden sizes, small batches); add_ln_kernel: its LayerNorm
 //   pool_kernel       masked mean over tokens, x / max(|x|, 1e-12)          (sentence-transformers)
 //
-// Activations are bf16 [tokens][hidden] row-major; every reduction (LN statistics, softmax
-// max/sum, MFMA accumulation, pooling) is fp32.  Tolerance vs the fp32 CPU oracle: 1 - cos <= 1e-3
-// (BASELINE.json north_star), measured ~1e-5 in tests/test_encoder_gpu.py.
+// Hidden state bf16 [tokens][hidden] row-major; QKV / context blocked [tokens/128][cols/32][128][32]
+// when the large-batch kernels produce them.  Every reduction (LN statistics, softmax max/sum,
+// MFMA accumulation, pooling) is fp32.  Tolerance vs the fp32 CPU oracle: 1 - cos <= 1e-3
+// (BASELINE.json north_star), measured ~5e-6 in tests/test_encoder_gpu.py.
 #include <float.h>
 #include <stdlib.h>
 #include <type_traits>
