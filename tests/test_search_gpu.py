@@ -253,3 +253,58 @@ def test_answer_is_invariant_under_row_permutation_and_batching(oracle_mod):
         for j in (0, k - 1):
             want = np.float32(oracle_mod.score_pair(Q[qi], X[I[qi, j]], metric=oracle_mod.METRIC_IP, dtype=oracle_mod.DTYPE_BF16))
             assert want.view(np.uint32) == D[qi, j].view(np.uint32)
+
+
+@pytest.mark.parametrize("metric,dtype,n,d,nq,k", [
+    ("ip", "bf16", 70000, 384, 1500, 10),      # 6 query tiles per slice: the 16x16x32 variant of the bench line
+    ("l2", "bf16", 70000, 384, 900, 10),       # the same with the accumulators started at -xx / 2
+    ("ip", "f32", 70000, 384, 800, 10),        # fp32 index: bf16 shadow + fp32 re-score
+    ("ip", "bf16", 90000, 128, 1000, 5),       # one k-block per row
+    ("ip", "bf16", 50000, 768, 520, 10),       # six k-blocks, four waves per workgroup (128-query tiles)
+    ("ip", "bf16", 60000, 384, 800, 100),      # K' = 128 lists
+])
+def test_mfma_bound_variant_matches_oracle(oracle_mod, metric, dtype, n, d, nq, k):
+    """More than two query tiles per slice: the plan takes the MFMA-bound kernel variant (16x16x32 MFMA, mid-unit
+    barrier, progress words) — the one the bench line runs.  Rows and queries are not unit norm."""
+    from rag_amd.index import MODE_FAST
+    rng = np.random.default_rng(n + d + nq)
+    X = _unit(rng, n, d) * rng.uniform(0.7, 1.3, size=(n, 1)).astype(np.float32)
+    Q = _unit(rng, nq, d) * rng.uniform(0.5, 2.0, size=(nq, 1)).astype(np.float32)
+    idx = _check(oracle_mod, X, Q, k, metric, dtype, mode=MODE_FAST)
+    st = idx.stats()
+    assert st["fast"] + st["exact"] == nq
+    if dtype == "bf16":
+        assert st["fast"] >= nq * 0.8, st
+
+
+_PLAN_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import oracle
+from rag_amd.index import FlatIndex, MODE_FAST
+rng = np.random.default_rng(5)
+def unit(n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+X, Q = unit(80000, 384), unit(700, 384)
+idx = FlatIndex(384, metric="ip", dtype="bf16"); idx.set_mode(MODE_FAST); idx.add(X)
+D, I = idx.search(Q, 10)
+Do, Io = oracle.search(X, Q, 10, metric=oracle.METRIC_IP, dtype=oracle.DTYPE_BF16)
+assert np.array_equal(I, Io) and np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+print("OK", idx.stats())
+"""
+
+
+@pytest.mark.parametrize("env", [{"MI_MFMA_M16": "0", "MI_MFMA_PD": "2"}, {"MI_MFMA_M16": "0", "MI_MFMA_PD": "3"},
+                                 {"MI_MFMA_NS": "8"}, {"MI_MFMA_NS": "64", "MI_MFMA_M16": "1", "MI_MFMA_PD": "2"}])
+def test_plan_overrides_do_not_change_the_answer(env):
+    """The scan's plan switches (kernel variant, prefetch distance, number of slices) pick a different kernel or
+    a different split of the rows; the answer stays bit-exact.  Read once per process: child processes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", _PLAN_CHILD % root], env=e, capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0 and "OK" in out.stdout, (env, out.stdout[-500:], out.stderr[-2000:])
