@@ -308,3 +308,38 @@ def test_plan_overrides_do_not_change_the_answer(env):
     e.update(env)
     out = subprocess.run([sys.executable, "-c", _PLAN_CHILD % root], env=e, capture_output=True, text=True, timeout=170)
     assert out.returncode == 0 and "OK" in out.stdout, (env, out.stdout[-500:], out.stderr[-2000:])
+
+
+def test_bench_size_properties(oracle_mod):
+    """BASELINE config 4 at its full single-GPU size (100M x 384 bf16, 10k queries, top-10), where the oracle cannot
+    follow: (1) best-first order; (2) every reported score is the canonical fp32 chain of the stored row (a sample,
+    rows regenerated on the CPU from the counter-based generator); (3) planted queries -- copies of corpus rows --
+    come back with their own row first; (4) a query's answer is the same whether it travels in the 10k batch (MFMA-
+    bound kernel variant) or in a batch of 7 (HBM-bound variant); (5) no query needed the exact fallback."""
+    import torch
+    from rag_amd.index import FlatIndex, MODE_FAST
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100e9:
+        pytest.skip("needs ~90 GB of HBM")
+    n, d, nq, k = 100_000_000, 384, 10_000, 10
+    idx = FlatIndex(d, metric="ip", dtype="bf16")
+    idx.set_mode(MODE_FAST)
+    idx.add_synthetic(n, seed=0)
+    Q = oracle_mod.synth_rows(1, 0, nq, d)
+    planted = [0, 123_456, 50_000_000, n - 1]
+    for j, r in enumerate(planted):
+        Q[j] = oracle_mod.synth_rows(0, r, 1, d)[0]
+    D, I = idx.search(Q, k)
+    st = idx.stats()
+    assert st["fast"] == nq and st["exact"] == 0, st
+    assert np.all(D[:, :-1] >= D[:, 1:]) and I.min() >= 0 and I.max() < n
+    for j, r in enumerate(planted):
+        assert I[j, 0] == r, (j, r, I[j])
+    for qi in (0, 3, 17, 5000, nq - 1):
+        for j in (0, 4, k - 1):
+            x = oracle_mod.synth_rows(0, int(I[qi, j]), 1, d)[0]
+            want = np.float32(oracle_mod.score_pair(Q[qi], x, metric=oracle_mod.METRIC_IP, dtype=oracle_mod.DTYPE_BF16))
+            assert want.view(np.uint32) == D[qi, j].view(np.uint32), (qi, j)
+    sub = [1, 4, 99, 2500, 7777, 9000, nq - 1]
+    D7, I7 = idx.search(Q[sub], k)
+    assert np.array_equal(I7, I[sub]) and np.array_equal(D7.view(np.uint32), D[sub].view(np.uint32))
