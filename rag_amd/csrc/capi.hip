@@ -32,6 +32,8 @@ int mi_ctx_device(mi_ctx* ctx) { return ctx->device; }
 hipStream_t mi_ctx_stream(mi_ctx* ctx) { return ctx->stream; }
 
 #define MI_ROW_SLACK 128
+// host-buffer searches whose queries and results both fit in this go through a pinned block of the index
+#define MI_PIN_BYTES (64u << 10)
 
 // grow-only device buffer
 struct DevBuf {
@@ -64,6 +66,8 @@ struct mi_index {
     float* xx = nullptr;        // [cap_rows] canonical squared norms
     float* max_xx = nullptr;    // device scalar: max over rows of xx
     std::mutex mu;
+    // pinned host staging for small host-buffer searches (MI_PIN_BYTES, allocated by the first one)
+    void* pin = nullptr;
     // recorded behind every add on the stream that carried it; a search on another stream waits on it
     hipEvent_t ev_data = nullptr;
     // search workspace (grow-only)
@@ -78,6 +82,15 @@ struct mi_index {
     int last_launches = 0;
     size_t elem() const { return dtype == MI_DTYPE_F32 ? 4 : 2; }
 };
+
+// the index's pinned host block: MI_PIN_BYTES of staging, then one 256-byte line for the certificate's fail count
+static int ensure_pin(mi_index* x)
+{
+    if (x->pin) return MI_OK;
+    hipError_t e = hipHostMalloc(&x->pin, MI_PIN_BYTES + 256, hipHostMallocDefault);
+    if (e != hipSuccess) { x->pin = nullptr; mi_set_error("hipHostMalloc failed: %s", hipGetErrorString(e)); return MI_ERR_OOM; }
+    return MI_OK;
+}
 
 struct DeviceGuard {
     explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); want = dev; }
@@ -170,6 +183,7 @@ extern "C" void mi_index_destroy(mi_index* idx)
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t ev : idx->ev_pool) (void)hipEventDestroy(ev);
     if (idx->ev_data) (void)hipEventDestroy(idx->ev_data);
+    if (idx->pin) (void)hipHostFree(idx->pin);
     delete idx;
 }
 
@@ -531,9 +545,11 @@ static int search_dev_locked(mi_index* x, int64_t nq64, const float* q_dev, int 
     }
     MI_TRY(mi_launch_mfma_certify(st, &plan, x->metric, nq, k, eps_acc, eps_round, x->qq.as<float>(), x->max_xx,
                                   x->cnts.as<int32_t>(), x->thrs.as<float>(), out_s, out_i, over_flags, fail_list, fail_count));
-    int32_t nfail = 0;
-    MI_HIP(hipMemcpyAsync(&nfail, fail_count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MI_TRY(ensure_pin(x));
+    volatile int32_t* nfail_pin = reinterpret_cast<int32_t*>(static_cast<char*>(x->pin) + MI_PIN_BYTES);
+    MI_HIP(hipMemcpyAsync(const_cast<int32_t*>(nfail_pin), fail_count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     MI_HIP(hipStreamSynchronize(st));
+    const int32_t nfail = *nfail_pin;
     x->st_fast += nq - nfail;
     if (nfail > 0) {
         // certificate failed for nfail queries: re-run exactly those on the exact path
@@ -569,13 +585,30 @@ extern "C" int mi_index_search(mi_index* idx, int64_t nq, const float* q_host, i
     std::lock_guard<std::mutex> lk(idx->mu);
     DeviceGuard g(idx->ctx->device);
     hipStream_t st = idx->ctx->stream;
-    MI_TRY(idx->q_in.ensure((size_t)nq * idx->d * sizeof(float)));
-    MI_TRY(idx->out_s.ensure((size_t)nq * k * sizeof(float)));
-    MI_TRY(idx->out_i.ensure((size_t)nq * k * sizeof(int64_t)));
-    MI_HIP(hipMemcpyAsync(idx->q_in.p, q_host, (size_t)nq * idx->d * sizeof(float), hipMemcpyHostToDevice, st));
-    MI_TRY(search_dev_locked(idx, nq, idx->q_in.as<float>(), k, idx->out_s.as<float>(), idx->out_i.as<int64_t>(), st));
-    MI_HIP(hipMemcpyAsync(out_scores, idx->out_s.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
-    MI_HIP(hipMemcpyAsync(out_ids, idx->out_i.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    const size_t q_bytes = (size_t)nq * idx->d * sizeof(float);
+    const size_t s_bytes = (size_t)nq * k * sizeof(float), i_bytes = (size_t)nq * k * sizeof(int64_t);
+    const size_t i_off = (s_bytes + 255) & ~(size_t)255;      // ids follow the scores in one buffer: one copy back
+    MI_TRY(idx->q_in.ensure(q_bytes));
+    MI_TRY(idx->out_s.ensure(i_off + i_bytes));
+    float* ds = idx->out_s.as<float>();
+    int64_t* di = reinterpret_cast<int64_t*>(idx->out_s.as<char>() + i_off);
+    if (q_bytes <= MI_PIN_BYTES && i_off + i_bytes <= MI_PIN_BYTES) {
+        // the interactive case (a query or a handful): pageable copies cost a staging hop and a sync each inside the
+        // runtime, so go through our own pinned block, one copy each way
+        MI_TRY(ensure_pin(idx));
+        memcpy(idx->pin, q_host, q_bytes);
+        MI_HIP(hipMemcpyAsync(idx->q_in.p, idx->pin, q_bytes, hipMemcpyHostToDevice, st));
+        MI_TRY(search_dev_locked(idx, nq, idx->q_in.as<float>(), k, ds, di, st));
+        MI_HIP(hipMemcpyAsync(idx->pin, idx->out_s.p, i_off + i_bytes, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipStreamSynchronize(st));
+        memcpy(out_scores, idx->pin, s_bytes);
+        memcpy(out_ids, static_cast<char*>(idx->pin) + i_off, i_bytes);
+        return MI_OK;
+    }
+    MI_HIP(hipMemcpyAsync(idx->q_in.p, q_host, q_bytes, hipMemcpyHostToDevice, st));
+    MI_TRY(search_dev_locked(idx, nq, idx->q_in.as<float>(), k, ds, di, st));
+    MI_HIP(hipMemcpyAsync(out_scores, ds, s_bytes, hipMemcpyDeviceToHost, st));
+    MI_HIP(hipMemcpyAsync(out_ids, di, i_bytes, hipMemcpyDeviceToHost, st));
     MI_HIP(hipStreamSynchronize(st));
     return MI_OK;
 }
