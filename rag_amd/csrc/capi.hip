@@ -400,10 +400,11 @@ static int exact_search(mi_index* x, hipStream_t st, const float* q_canon, const
     // dense workspace: up to 256M scores (1 GiB); queries in chunks of <= 4096
     const int64_t ws_elems = (int64_t)256 << 20;
     const int qc_max = nq < 4096 ? nq : 4096;
-    int64_t seg_rows = ws_elems / qc_max;
-    if (seg_rows > n) seg_rows = n;
+    int64_t seg_rows = ws_elems / qc_max / 256 * 256;
     if (seg_rows > ((int64_t)65535 * 256)) seg_rows = (int64_t)65535 * 256;
-    seg_rows = seg_rows / 256 * 256;
+    // a short index is ONE segment: round its length up, not down (2,000 rows used to become 1,792 + 208,
+    // two scans, two selects and two merges)
+    if (seg_rows > (n + 255) / 256 * 256) seg_rows = (n + 255) / 256 * 256;
     if (seg_rows < 256) seg_rows = 256;
     MI_TRY(x->dense.ensure((size_t)qc_max * seg_rows * sizeof(float)));
     const bool multi = n > seg_rows;
@@ -422,11 +423,24 @@ static int exact_search(mi_index* x, hipStream_t st, const float* q_canon, const
             if (timed) MI_TRY(ev_begin(x, st));
             MI_TRY(mi_launch_scan_dense(st, x->rows, x->dtype, r0, nr, x->d_pad, q_canon + (int64_t)q0 * x->d_pad, qc, S, seg_rows));
             if (timed) MI_TRY(ev_end(x, st));
-            if (!multi) {
-                MI_TRY(mi_launch_select_dense(st, S, seg_rows, nr, x->xx + r0, qq + q0, x->metric, qc, k, x->id_base + r0, os, oi, k));
+            // where the segment's k best go: the answer itself, or the right half of the running pair
+            float* ds = multi ? x->pair_s.as<float>() + k : os;
+            int64_t* di = multi ? x->pair_i.as<int64_t>() + k : oi;
+            const int64_t dstride = multi ? 2 * k : k;
+            int seg_len = nr;
+            const int pieces = mi_select_dense_pieces(nr, qc, k, &seg_len);
+            if (pieces == 1) {
+                MI_TRY(mi_launch_select_dense(st, S, seg_rows, nr, nr, x->xx + r0, qq + q0, x->metric, qc, k, x->id_base + r0, ds, di, dstride));
             } else {
-                MI_TRY(mi_launch_select_dense(st, S, seg_rows, nr, x->xx + r0, qq + q0, x->metric, qc, k, x->id_base + r0,
-                                              x->pair_s.as<float>() + k, x->pair_i.as<int64_t>() + k, 2 * k));
+                // few queries, long segment: one workgroup per (query, piece), then one merge of the pieces' lists
+                const int64_t m = (int64_t)pieces * k;
+                MI_TRY(x->part_s.ensure((size_t)qc * m * sizeof(float)));
+                MI_TRY(x->part_i.ensure((size_t)qc * m * sizeof(int64_t)));
+                MI_TRY(mi_launch_select_dense(st, S, seg_rows, nr, seg_len, x->xx + r0, qq + q0, x->metric, qc, k, x->id_base + r0,
+                                              x->part_s.as<float>(), x->part_i.as<int64_t>(), m));
+                MI_TRY(mi_launch_merge(st, x->metric, qc, (int)m, x->part_s.as<float>(), x->part_i.as<int64_t>(), m, k, ds, di, dstride));
+            }
+            if (multi) {
                 const bool last = r0 + seg_rows >= n;
                 if (!last) MI_TRY(mi_launch_merge(st, x->metric, qc, 2 * k, x->pair_s.as<float>(), x->pair_i.as<int64_t>(), 2 * k, k,
                                                   x->pair_s.as<float>(), x->pair_i.as<int64_t>(), 2 * k));
@@ -472,6 +486,10 @@ static int search_dev_locked(mi_index* x, int64_t nq64, const float* q_dev, int 
     if (x->mode != MI_MODE_EXACT && x->d_pad_scan != 0 && mi_mfma_supported(x->d_pad_scan, k) &&
         mi_mfma_make_plan(n, x->d_pad_scan, nq, k, &plan) == MI_OK)
         fast = true;
+    // A handful of queries over up to a million rows is a latency problem: the MFMA scan has ~0.2 ms of
+    // start-up per launch whatever the grid (measured: 200,000 rows x 1 query, 8 ... 1536 slices, 235-315 us),
+    // the exact kernels stream the same rows in less (AUTO only: FAST still forces the MFMA scan).
+    if (fast && x->mode == MI_MODE_AUTO && nq <= 4 && n <= ((int64_t)1 << 20)) fast = false;
     if (x->mode == MI_MODE_FAST && !fast) {
         mi_set_error("search: MI_MODE_FAST requested but the MFMA path does not cover this index (dtype=%d metric=%d d=%d n=%lld k=%d)",
                      x->dtype, x->metric, x->d, (long long)n, k);

@@ -27,9 +27,12 @@ int mi_launch_scan_dense(hipStream_t st, const void* rows, int dtype, int64_t ro
                          int d_pad, const float* q_canon, int nq, float* S, int64_t s_stride);
 // Per query: exact top-k of one dense segment, best-first, written at out[q*out_stride + j].
 // xx points at the segment's first row; id0 = id of the segment's first row.
-int mi_launch_select_dense(hipStream_t st, const float* S, int64_t s_stride, int nrows,
+// seg_len < nrows: the segment is selected in pieces of seg_len rows, grid (nq, pieces); piece p's k best
+// land at out[q * out_stride + p * k ..] and the caller merges them (mi_select_dense_pieces picks seg_len).
+int mi_launch_select_dense(hipStream_t st, const float* S, int64_t s_stride, int nrows, int seg_len,
                            const float* xx, const float* qq, int metric, int nq, int k,
                            int64_t id0, float* out_s, int64_t* out_i, int64_t out_stride);
+int mi_select_dense_pieces(int nrows, int nq, int k, int* seg_len);
 // Per query: merge m (<= 4096) (score,id) entries (id < 0 = padding) into the k best.
 int mi_launch_merge(hipStream_t st, int metric, int64_t nq, int m, const float* in_s,
                     const int64_t* in_i, int64_t in_stride, int k, float* out_s, int64_t* out_i,

@@ -983,8 +983,11 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
     // >= ~1024 workgroups in the grid (four per CU over the launch), one slice per XCD at least
     int ns = (int)mi_round_up((1024 + nqt - 1) / nqt, 8);
     if (ns > spg_max * gmax) ns = spg_max * gmax;
-    // at least ~32 tiles per slice so the running thresholds have time to tighten
-    while (ns > 8 && n / ns < 32 * MF_TILE_R) ns -= 8;
+    // at least ~32 tiles per slice so the running thresholds have time to tighten; with one or two
+    // query tiles the scan is a latency problem instead (200,000 rows x 1 query: 48 slices took
+    // 293 us on 48 CUs), so there 8 tiles per slice are enough - the lists are rescored exactly anyway
+    const int min_tiles = (nqt <= 2) ? 8 : 32;
+    while (ns > 8 && n / ns < (int64_t)min_tiles * MF_TILE_R) ns -= 8;
     if (ns < 8) ns = 8;
     if (const char* e = getenv("MI_MFMA_NS")) {
         const int v = atoi(e) / 8 * 8;

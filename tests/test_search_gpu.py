@@ -41,6 +41,20 @@ def test_exact_path_matches_oracle(oracle_mod, metric, dtype, n, d, nq, k):
     _check(oracle_mod, _unit(rng, n, d), _unit(rng, nq, d), k, metric, dtype, mode=MODE_EXACT)
 
 
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("n,d,nq,k", [(2000, 384, 1, 5), (20000, 384, 1, 5), (50000, 100, 3, 100), (200000, 384, 2, 5),
+                                       (9000, 384, 4, 1000), (4097, 64, 1, 7)])
+def test_few_queries_take_the_latency_kernels(oracle_mod, metric, dtype, n, d, nq, k):
+    """nq <= 4: one-wave dense scan, select in pieces of >= 4096 rows + one merge (search_exact.hip); AUTO mode
+    routes such searches to the exact path up to 2^20 rows."""
+    rng = np.random.default_rng(n + d + nq)
+    X = _unit(rng, n, d)
+    X[n // 2] = X[3]                                 # a tie across pieces
+    idx = _check(oracle_mod, X, np.concatenate([X[3:4], _unit(rng, nq - 1, d)]) if nq > 1 else X[3:4].copy(), k, metric, dtype)
+    assert idx.last_scan_time()["kind"] == "exact_f32"
+
+
 def test_k_larger_than_n_and_empty(oracle_mod):
     rng = np.random.default_rng(1)
     X, Q = _unit(rng, 3, 32), _unit(rng, 2, 32)
