@@ -486,9 +486,10 @@ static int search_dev_locked(mi_index* x, int64_t nq64, const float* q_dev, int 
     if (x->mode != MI_MODE_EXACT && x->d_pad_scan != 0 && mi_mfma_supported(x->d_pad_scan, k) &&
         mi_mfma_make_plan(n, x->d_pad_scan, nq, k, &plan) == MI_OK)
         fast = true;
-    // A handful of queries over up to a million rows is a latency problem: the MFMA scan has ~0.2 ms of
-    // start-up per launch whatever the grid (measured: 200,000 rows x 1 query, 8 ... 1536 slices, 235-315 us),
-    // the exact kernels stream the same rows in less (AUTO only: FAST still forces the MFMA scan).
+    // A handful of queries over up to a million rows is a latency problem: the MFMA route is scan + finish +
+    // certify + a D2H of the fail count (~130 us beyond the scan), the exact kernels are scan + select + merge.
+    // Measured per call, 1 query, L2 (f32 / bf16 index): 200,000 rows 115 / 94 us exact vs 183 / 181 us MFMA;
+    // 10^6 rows 372 / 245 vs 344 / 343 (AUTO only: FAST still forces the MFMA scan).
     if (fast && x->mode == MI_MODE_AUTO && nq <= 4 && n <= ((int64_t)1 << 20)) fast = false;
     if (x->mode == MI_MODE_FAST && !fast) {
         mi_set_error("search: MI_MODE_FAST requested but the MFMA path does not cover this index (dtype=%d metric=%d d=%d n=%lld k=%d)",

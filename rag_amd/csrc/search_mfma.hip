@@ -162,6 +162,9 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     __shared__ __attribute__((aligned(1024))) char lds[MF_LDS_BYTES + MF_TRACE_LDS];
 
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+#ifdef MF_TRACE
+    const uint32_t t_entry = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5;
@@ -281,10 +284,14 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     };
 
     // ---- per-lane filter state, replicated in lanes (col) and (col + 32)
-    float thr = -__builtin_inff();
+    // Lanes of padding queries (q >= nq: zero vectors) start at +inf and never take a row.  Left at -inf they
+    // cost more than the real ones: under L2 every row scores -xx/2, equal up to rounding, so their lists
+    // kept compacting for the first three tiles of every slice (75 us each, traced at 200,000 rows x 1 query).
+    float thr = (qglob < nq) ? -__builtin_inff() : __builtin_inff();
     int cnt = 0;
     uint64_t* const list = lists + ((int64_t)slice * nq_pad + qglob) * CAP;
-    float thr2[2] = {-__builtin_inff(), -__builtin_inff()};       // 16x16x32: the lane's two queries
+    float thr2[2] = {(qbase + l15 < nq) ? -__builtin_inff() : __builtin_inff(),       // 16x16x32: the lane's two queries
+                     (qbase + 16 + l15 < nq) ? -__builtin_inff() : __builtin_inff()};
     int cnt2[2] = {0, 0};
 
     f32x16 acc[M16 ? 1 : 4];
@@ -605,6 +612,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
             if (lane == 0) tr[(u - MF_TRACE_U0) * 8 + k] = t;
         }
     };
+    const uint32_t t_loop = (uint32_t)__builtin_amdgcn_s_memtime();
 #else
     auto stamp = [&](int) __attribute__((always_inline)) {};
 #endif
@@ -704,6 +712,9 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     }
 #ifdef MF_TRACE
     if (tslot >= 0) {
+        // start-up trace (MF_TRACE_U0 = 0, < 63 units per slice): the last unit slot carries kernel entry,
+        // loop entry and loop exit
+        if (lane == 0) { tr[63 * 8 + 0] = t_entry; tr[63 * 8 + 1] = t_loop; tr[63 * 8 + 2] = (uint32_t)__builtin_amdgcn_s_memtime(); }
         __builtin_amdgcn_s_waitcnt(0);
         for (int i = lane; i < 512; i += 64) (&mf_trace_buf[tslot][wave][0][0])[i] = tr[i];
     }
