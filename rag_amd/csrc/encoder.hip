@@ -1570,7 +1570,16 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
 
     // hidden size 384: the two N = 384 projections run fused with their LayerNorm (MI_GEMM_LN=0: separate kernels)
     static const bool ln_off = getenv("MI_GEMM_LN") && atoi(getenv("MI_GEMM_LN")) == 0;
-    const bool fused_ln = !ln_off && H == LN_N && I % 64 == 0;
+    // The fused kernels own a 128-row tile each and walk all of K (and I) inside one workgroup: built for bulk
+    // embedding, where there are hundreds of tiles.  A query or a few chunks fill one to a few dozen of the 256
+    // CUs and wait 97 us per layer on one workgroup's pipeline; the general GEMMs spread the same tile over the
+    // output columns instead.  Measured (MiniLM-L6, device time per call): 16 tokens 645 -> 357 us, 4,096 tokens
+    // 737 -> 517, 16,384 tokens 885 vs 880, 65,536 tokens 2,065 vs 2,598.  MI_ENC_LATENCY_TOKENS moves the
+    // hand-over (0: always the bulk kernels); read per call so a test can flip it.
+    int64_t latency_tokens = 12288;
+    if (const char* s = getenv("MI_ENC_LATENCY_TOKENS")) latency_tokens = atoll(s);
+    const bool bulk = T >= latency_tokens;
+    const bool fused_ln = !ln_off && bulk && H == LN_N && I % 64 == 0;
     static const bool ffn_off = getenv("MI_FFN_FUSED") && atoi(getenv("MI_FFN_FUSED")) == 0;
     const bool fused_ffn = fused_ln && !ffn_off && I == 1536;
     static const bool front_off = getenv("MI_FFN_FRONT") && atoi(getenv("MI_FFN_FRONT")) == 0;

@@ -14,12 +14,24 @@ def _cos_err(a, b):
     return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
 
 
+@pytest.fixture(params=["bulk", "latency"])
+def kernel_family(request, monkeypatch):
+    """encoder.hip hands calls below MI_ENC_LATENCY_TOKENS (default 12288) to the general GEMMs and the rest to the
+    fused per-tile kernels; the variable is read per call.  The parity inputs are small (the oracle is a scalar
+    port), so "bulk" pins the hand-over at 0 to hold the fused kernels to the bar as well."""
+    if request.param == "bulk":
+        monkeypatch.setenv("MI_ENC_LATENCY_TOKENS", "0")
+    else:
+        monkeypatch.delenv("MI_ENC_LATENCY_TOKENS", raising=False)
+    return request.param
+
+
 def _cfgs(oracle, *vals):
     from rag_amd._capi import BertConfig
     return BertConfig(*vals), oracle.BertConfig(*vals)
 
 
-def test_matches_bertmodel_fixture(oracle_mod):
+def test_matches_bertmodel_fixture(oracle_mod, kernel_family):
     from rag_amd.embeddings import Encoder
     g = np.load(GOLD)
     c = [int(v) for v in g["config"]]
@@ -32,7 +44,7 @@ def test_matches_bertmodel_fixture(oracle_mod):
 
 
 @pytest.mark.parametrize("B,L", [(3, 256), (5, 100), (9, 33), (2, 512), (1, 1)])
-def test_minilm_dims_match_oracle(oracle_mod, B, L):
+def test_minilm_dims_match_oracle(oracle_mod, kernel_family, B, L):
     from rag_amd.embeddings import Encoder
     from rag_amd.encoder_weights import random_blob
     cfg, ocfg = _cfgs(oracle_mod, 2000, 384, 6, 12, 1536, 512, 2, 1e-12, 1)
@@ -177,6 +189,7 @@ def test_unfused_kernel_paths_in_a_child_process(env):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ)
+    e["MI_ENC_LATENCY_TOKENS"] = "0"                       # small input: keep it on the bulk kernels the switches act on
     e.update(env)
     out = subprocess.run([sys.executable, "-c", _CHILD % root], env=e, capture_output=True, text=True, timeout=170)
     assert out.returncode == 0, out.stderr[-2000:]
