@@ -235,8 +235,12 @@ __device__ __forceinline__ void lds_read2(bf16x8& a, bf16x8& b, unsigned addr)
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096" : "=&v"(a), "=&v"(b) : "v"(addr));
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+// NST = 1: the form above.  NST = 4 (small grids, one workgroup per CU at most): a ring of four stages with the
+// loads of k-steps kt + 1 .. kt + 3 in flight while kt is multiplied.  With hundreds of tiles the four co-resident
+// workgroups of NST = 1 hide each other's load latency; with a few tiles (a query, a few chunks) nothing does, and
+// every k-step of NST = 1 costs a full trip to memory: 16 x 384 x 1152 took 9.8 us, K = 1536 three times that.
+template <int EPI, int NST>
+__global__ __launch_bounds__(256, NST == 1 ? 4 : 1) void gemm_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         const float* __restrict__ bias, const uint16_t* __restrict__ resid, uint16_t* __restrict__ C,
         int M, int N, int K, int n_tiles, int m_tiles)
 {
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const uint16_t* __res
     // overlap its loads with its MFMAs; four workgroups per CU (36 KB LDS, <= 128 registers) do.
     // Measured against the double-buffered two-per-CU form of this kernel: see DESIGN.md.
     constexpr int PARK = (EPI == EPI_RESID) ? 64 * GM_TS32 : 64 * GM_TS16;     // half a tile (64 rows) parked at a time
-    constexpr int LDS_BYTES = PARK > GM_STAGE ? PARK : GM_STAGE;
+    constexpr int LDS_BYTES = PARK > NST * GM_STAGE ? PARK : NST * GM_STAGE;
     __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -275,11 +279,12 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const uint16_t* __res
     }
     auto issue = [&](int kt) {
         const int koff = kt * (GM_BK * 2);
+        char* const stg = lds + (kt & (NST - 1)) * GM_STAGE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = wave * 4 + i;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + koff), (lds_ptr_t)(lds + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + koff), (lds_ptr_t)(lds + 16384 + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + koff), (lds_ptr_t)(stg + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w_src[i] + koff), (lds_ptr_t)(stg + 16384 + p * 1024), 16, 0, 0);
         }
     };
 
@@ -294,14 +299,30 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const uint16_t* __res
 
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     const int sw = (col >> 1) & 7;
-    const unsigned a_off = lds_base + (unsigned)((wm * 64 + col) * 128);
-    const unsigned w_off = lds_base + (unsigned)(16384 + (wn * 64 + col) * 128);
+    const unsigned a_off0 = lds_base + (unsigned)((wm * 64 + col) * 128);
+    const unsigned w_off0 = lds_base + (unsigned)(16384 + (wn * 64 + col) * 128);
 
     const int nkt = K / GM_BK;
+    if constexpr (NST > 1) {
+        for (int s = 0; s < NST - 1 && s < nkt; ++s) issue(s);
+    }
     for (int kt = 0; kt < nkt; ++kt) {
-        issue(kt);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (NST == 1) {
+            issue(kt);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            // stage (kt + NST - 1) % NST held k-step kt - 1: everyone left it at the barrier that closed kt - 1
+            if (kt + NST - 1 < nkt) issue(kt + NST - 1);
+            // k-step kt has landed once at most the younger steps' loads (8 per step and wave) are outstanding
+            const int younger = (nkt - 1 - kt < NST - 1) ? nkt - 1 - kt : NST - 1;
+            if (younger >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
+        const unsigned a_off = a_off0 + (unsigned)((kt & (NST - 1)) * GM_STAGE);
+        const unsigned w_off = w_off0 + (unsigned)((kt & (NST - 1)) * GM_STAGE);
         bf16x8 af[2][2], wf[2][2];       // [parity][block]: rows +0 and +32 (offset 4096 B)
         lds_read2(af[0][0], af[0][1], a_off + (((0 + h) ^ sw) << 4));
         lds_read2(wf[0][0], wf[0][1], w_off + (((0 + h) ^ sw) << 4));
@@ -1532,7 +1553,12 @@ static bool launch_gemm(hipStream_t st, const uint16_t* A, const uint16_t* W, co
     if (launch_gemm_ws<EPI>(st, A, W, bias, resid, C, M, N, K, want_blocked)) return want_blocked;
     const int n_tiles = N / GM_BN, m_tiles = (M + GM_BM - 1) / GM_BM;
     const unsigned grid = (unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles);
-    gemm_bf16_kernel<EPI><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K, n_tiles, m_tiles);
+    // a grid that cannot put four workgroups on every CU takes the ring-of-four form (MI_GEMM_RING=0: never)
+    static const bool ring_off = getenv("MI_GEMM_RING") && atoi(getenv("MI_GEMM_RING")) == 0;
+    if (!ring_off && m_tiles * n_tiles <= 512)
+        gemm_bf16_kernel<EPI, 4><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K, n_tiles, m_tiles);
+    else
+        gemm_bf16_kernel<EPI, 1><<<grid, 256, 0, st>>>(A, W, bias, resid, C, M, N, K, n_tiles, m_tiles);
     return false;
 }
 
