@@ -181,7 +181,9 @@ print("WORST", worst)
 
 
 @pytest.mark.parametrize("env", [{"MI_FFN_FRONT": "0"}, {"MI_FFN_FUSED": "0"}, {"MI_FFN_FUSED": "0", "MI_GEMM_WS": "0"},
-                                 {"MI_FFN_FUSED": "0", "MI_GEMM_LN": "0"}])
+                                 {"MI_FFN_FUSED": "0", "MI_GEMM_LN": "0"},
+                                 {"MI_FFN_FUSED": "0", "MI_GEMM_LN": "0", "MI_GEMM_RING": "0"},
+                                 {"MI_FFN_FUSED": "0", "MI_GEMM_WS": "0", "MI_GEMM_RING": "0"}])
 def test_unfused_kernel_paths_in_a_child_process(env):
     """The kernels the fused ones replaced stay in the library as fallbacks (other shapes, switches read once per
     process): each combination runs in its own process and is held to the same bar."""
