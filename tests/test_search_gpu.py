@@ -34,7 +34,10 @@ def _check(oracle, X, Q, k, metric, dtype, mode=None, id_base=0):
 
 @pytest.mark.parametrize("metric", ["ip", "l2"])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("n,d,nq,k", [(1000, 384, 7, 5), (5000, 64, 33, 10), (300, 100, 3, 4), (70000, 384, 20, 10)])
+@pytest.mark.parametrize("n,d,nq,k", [(1000, 384, 7, 5), (5000, 64, 33, 10), (300, 100, 3, 4), (70000, 384, 20, 10),
+                                       # > 64 queries: one select workgroup per query over the whole segment
+                                       # (rank words in registers up to 32768 rows, recomputed per pass beyond)
+                                       (6000, 64, 70, 10), (40000, 64, 70, 10)])
 def test_exact_path_matches_oracle(oracle_mod, metric, dtype, n, d, nq, k):
     from rag_amd.index import MODE_EXACT
     rng = np.random.default_rng(n + d)
