@@ -23,7 +23,7 @@
  *     (hipSetDevice) and takes the handle's mutex, so it may be called from arbitrary
  *     host threads (LangChain RunnableParallel workers, Gradio handlers).
  *   - "*_dev" variants take raw device pointers (e.g. torch.Tensor.data_ptr()) and a
- *     hipStream_t passed as void* (NULL = the ctx's own stream); they enqueue work and
+ *     hipStream_t passed as void* (NULL = the ctx's own stream, MI_STREAM_LEGACY = the null stream); they enqueue work and
  *     return without a host sync unless noted.  Host-pointer variants are synchronous.
  *   - the library has NO CPU fallback: without a gfx950 device mi_init fails with
  *     MI_ERR_NO_DEVICE.
@@ -72,6 +72,10 @@ enum {
 };
 
 #define MI_MAX_K 2048
+/* `stream` argument of the *_dev entry points: the legacy default ("null") stream.  NULL selects the ctx's own
+ * (non-blocking) stream, so a caller whose tensors live on the null stream -- PyTorch's default stream has
+ * handle 0 -- passes this instead.  Same value as hipStreamLegacy. */
+#define MI_STREAM_LEGACY ((void*)1)
 
 /* ------------------------------------------------------------------ context */
 
@@ -138,10 +142,20 @@ int  mi_index_last_scan_time(const mi_index* idx, float* out_ms, int* out_launch
 
 /* Merges `nlists` best-first lists per query into one best-first list of length k
  * (the step after the all-gather of per-GPU top-k).
- * in_scores [nq][nlists*k_in] fp32, in_ids same shape int64 (id < 0 = padding), all device. */
+ * in_scores [nq][nlists*k_in] fp32, in_ids same shape int64 (id < 0 = padding), all device.
+ * Any nlists*k_in < 2^24 and k <= MI_MAX_K: more than 4096 entries per query are merged in passes
+ * through scratch buffers owned by the ctx (allocated on first use). */
 int  mi_topk_merge_dev(mi_ctx* ctx, int metric, int64_t nq, int nlists, int k_in,
                        const float* in_scores_dev, const int64_t* in_ids_dev,
                        int k, float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+
+/* The same for lists still packed as the all-gather leaves them (ONE collective).  A rank's block is
+ * [nq][k] fp32 scores followed, at ids_offset, by [nq][k] int64 ids; block_bytes is the all-gather's per-rank
+ * message.  A rank points mi_index_search_dev's outputs into its block, gathers the `nlists` blocks rank-major
+ * into packed_dev (8-byte aligned) and merges them in place: no transpose, no second collective. */
+int  mi_topk_packed_layout(int64_t nq, int k, size_t* ids_offset, size_t* block_bytes);
+int  mi_topk_merge_packed_dev(mi_ctx* ctx, int metric, int64_t nq, int nlists, int k_in, const void* packed_dev,
+                              int k, float* out_scores_dev, int64_t* out_ids_dev, void* stream);
 
 /* ------------------------------------------------------------------ encoder
  * Replaces HuggingFaceEmbeddings(...).embed_documents / embed_query
@@ -154,7 +168,7 @@ typedef struct {
     int32_t vocab_size;               /* 30522 */
     int32_t hidden_size;              /* 384; must be a multiple of 128 and <= 1024 */
     int32_t num_hidden_layers;        /* 6 */
-    int32_t num_attention_heads;      /* 12; head size must be 32 or 64 */
+    int32_t num_attention_heads;      /* 12; hidden_size / heads must be 32 */
     int32_t intermediate_size;        /* 1536; multiple of 128 */
     int32_t max_position_embeddings;  /* 512 */
     int32_t type_vocab_size;          /* 2 */
@@ -176,7 +190,36 @@ int  mi_encoder_encode(mi_encoder* enc, int64_t B, int L, const int32_t* ids,
                        const int32_t* mask, float* out_emb);
 int  mi_encoder_encode_dev(mi_encoder* enc, int64_t B, int L, const int32_t* ids_dev,
                            const int32_t* mask_dev, float* out_emb_dev, void* stream);
-/* Timing of the last encode (all kernels), HIP events on its stream. */
+/* Ragged bulk embedding, the call FAISS.from_documents makes through embed_documents
+ * (advanced_rag.py:295): n sequences as one flat token array; sequence i is
+ * flat_ids[offsets[i] .. offsets[i+1]) (host int32 / int64 [n+1]); out_emb host fp32 [n][hidden]
+ * in INPUT order.  The library does what sentence-transformers' encode loop does above the
+ * boundary -- sort by length, cut into batches, pad each to its longest -- except that a batch is
+ * cut by a token budget (64K tokens) instead of 32 rows, so bulk calls run the fused bulk
+ * kernels whatever the length mix.  max_len > 0 truncates sequences (the tokenizer's
+ * max_seq_length, 256 for all-MiniLM-L6-v2); max_batch > 0 caps the rows per batch
+ * (encode_kwargs["batch_size"] when the caller sets it).  An empty sequence yields a zero vector. */
+int  mi_encoder_encode_ragged(mi_encoder* enc, int64_t n, const int32_t* flat_ids, const int64_t* offsets,
+                              int max_len, int max_batch, float* out_emb);
+
+/* Cross-encoder scoring of (query, passage) pairs: the rerank batch BASELINE config 5 feeds
+ * (README.md:27 and requirements.txt:24 name a reranker; advanced_rag.py has none).  Same encoder
+ * forward with token type ids, then transformers' BertPooler + BertForSequenceClassification head:
+ * logits = cls_w tanh(pooler_w h[CLS] + pooler_b) + cls_b.
+ * mi_encoder_set_head: host fp32 pooler_w [H][H], pooler_b [H], cls_w [num_labels][H], cls_b [num_labels].
+ * mi_encoder_classify: ids, type_ids (NULL = all 0), mask host int32 [B][L]; out_logits host fp32 [B][num_labels]. */
+int  mi_encoder_set_head(mi_encoder* enc, const float* pooler_w, const float* pooler_b,
+                         const float* cls_w, const float* cls_b, int num_labels);
+int  mi_encoder_classify(mi_encoder* enc, int64_t B, int L, const int32_t* ids, const int32_t* type_ids,
+                         const int32_t* mask, float* out_logits);
+int  mi_encoder_classify_dev(mi_encoder* enc, int64_t B, int L, const int32_t* ids_dev, const int32_t* type_ids_dev,
+                             const int32_t* mask_dev, float* out_logits_dev, void* stream);
+
+/* Counters since creation: out[0] sequences encoded, out[1] tokens processed (padding included),
+ * out[2] passes that ran the bulk kernel family (fused per-tile kernels, >= 12,288 tokens),
+ * out[3] passes that ran the latency family (general GEMMs). */
+int  mi_encoder_stats(const mi_encoder* enc, int64_t out[4]);
+/* Timing of the last encode pass (all kernels), HIP events on its stream. */
 int  mi_encoder_last_time(const mi_encoder* enc, float* out_ms);
 
 #ifdef __cplusplus

@@ -61,6 +61,8 @@ def lib():
         L.oracle_encoder_blob_elems.restype = i64
         L.oracle_encode.argtypes = [ctypes.POINTER(BertConfig), vp, i64, i32, vp, vp, vp, i32]
         L.oracle_encode.restype = i32
+        L.oracle_classify.argtypes = [ctypes.POINTER(BertConfig), vp, vp, i32, i64, i32, vp, vp, vp, vp, i32]
+        L.oracle_classify.restype = i32
         L.oracle_encode_taps.argtypes = [ctypes.POINTER(BertConfig), vp, i32, vp, vp, vp, vp, vp]
         L.oracle_encode_taps.restype = i32
         _lib = L
@@ -143,6 +145,26 @@ def encode(cfg: BertConfig, blob: np.ndarray, ids: np.ndarray, mask: np.ndarray,
     out = np.empty((B, cfg.hidden_size), dtype=np.float32)
     if lib().oracle_encode(ctypes.byref(cfg), _p(blob), B, L, _p(ids), _p(mask), _p(out), nthreads) != 0:
         raise ValueError("oracle_encode: bad arguments (token id out of range or L too long)")
+    return out
+
+
+def classify(cfg: BertConfig, blob: np.ndarray, head, ids: np.ndarray, types, mask: np.ndarray, nthreads: int = 0) -> np.ndarray:
+    """Cross-encoder logits [B][num_labels]; head = (pooler_w [H][H], pooler_b [H], cls_w [nl][H], cls_b [nl])."""
+    blob = np.ascontiguousarray(blob, dtype=np.float32)
+    assert blob.size == blob_elems(cfg), "weights blob size does not match the config"
+    pw, pb, cw, cb = (np.ascontiguousarray(a, dtype=np.float32) for a in head)
+    nl = cw.shape[0]
+    hflat = np.concatenate([pw.reshape(-1), pb.reshape(-1), cw.reshape(-1), cb.reshape(-1)])
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    mask = np.ascontiguousarray(mask, dtype=np.int32)
+    tp = None
+    if types is not None:
+        types = np.ascontiguousarray(types, dtype=np.int32)
+        tp = _p(types)
+    B, L = ids.shape
+    out = np.empty((B, nl), dtype=np.float32)
+    if lib().oracle_classify(ctypes.byref(cfg), _p(blob), _p(hflat), nl, B, L, _p(ids), tp, _p(mask), _p(out), nthreads) != 0:
+        raise ValueError("oracle_classify: bad arguments")
     return out
 
 

@@ -22,6 +22,9 @@
  *   :289-293  attention output dense + residual + LayerNorm
  *   :334-337  intermediate dense + erf-GELU (activations.py GELUActivation)
  *   :347-351  output dense + residual + LayerNorm
+ *   :96-100   token type ids: zeros for a bi-encoder, the segment ids of a cross-encoder pair
+ *   :451-463  BertPooler: tanh(W_p h[:, 0] + b_p)
+ *   :1118-1119 BertForSequenceClassification: logits = W_c pooled + b_c (dropout = identity in eval)
  * and sentence-transformers' Pooling(mean) + Normalize:
  *   sum_t h_t m_t / max(sum_t m_t, 1e-9);  x / max(||x||_2, 1e-12).
  *
@@ -95,8 +98,8 @@ static void layer_norm(float* x, const float* g, const float* b, int M, int H, f
 
 /* One chunk (sequence) forward.  ids/mask [L]; out [H].  Optional taps (may be NULL):
  * tap_emb [L][H] after the embedding LayerNorm, tap_layers [nl][L][H] after each layer. */
-static void encode_one(const oracle_bert_config* c, const float* blob, const int32_t* ids,
-                       const int32_t* mask, int L, float* out, float* tap_emb, float* tap_layers)
+static void encode_one(const oracle_bert_config* c, const float* blob, const int32_t* ids, const int32_t* types,
+                       const int32_t* mask, int L, float* out, float* tap_emb, float* tap_layers, float* cls_out)
 {
     const int H = c->hidden_size, I = c->intermediate_size, NH = c->num_attention_heads;
     const int DH = H / NH;
@@ -118,7 +121,7 @@ static void encode_one(const oracle_bert_config* c, const float* blob, const int
 
     for (int i = 0; i < L; ++i)
         for (int j = 0; j < H; ++j)
-            h[(size_t)i * H + j] = (word[(size_t)ids[i] * H + j] + type[j]) + pos[(size_t)i * H + j];
+            h[(size_t)i * H + j] = (word[(size_t)ids[i] * H + j] + type[(size_t)(types ? types[i] : 0) * H + j]) + pos[(size_t)i * H + j];
     layer_norm(h, eg, eb, L, H, c->layer_norm_eps);
     if (tap_emb) memcpy(tap_emb, h, (size_t)L * H * sizeof(float));
 
@@ -165,6 +168,9 @@ static void encode_one(const oracle_bert_config* c, const float* blob, const int
         if (tap_layers) memcpy(tap_layers + (size_t)l * L * H, h, (size_t)L * H * sizeof(float));
     }
 
+    if (cls_out) memcpy(cls_out, h, (size_t)H * sizeof(float));     /* final hidden state of the [CLS] token (position 0) */
+    if (!out) { free(h); free(q); free(k); free(v); free(ctx); free(t); free(mid); free(prob); return; }
+
     /* masked mean pool + L2 normalise */
     float msum = 0;
     for (int i = 0; i < L; ++i) msum += (float)(mask[i] != 0);
@@ -197,7 +203,44 @@ int oracle_encode(const oracle_bert_config* c, const float* blob, int64_t B, int
 #endif
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
     for (int64_t b = 0; b < B; ++b)
-        encode_one(c, blob, ids + b * L, mask + b * L, L, out + b * c->hidden_size, NULL, NULL);
+        encode_one(c, blob, ids + b * L, NULL, mask + b * L, L, out + b * c->hidden_size, NULL, NULL, NULL);
+    return 0;
+}
+
+/* Cross-encoder logits: encoder forward with token type ids, BertPooler, classifier.
+ * head = pooler_w[H][H] pooler_b[H] cls_w[nl][H] cls_b[nl]; types may be NULL (all 0); out [B][nl]. */
+int oracle_classify(const oracle_bert_config* c, const float* blob, const float* head, int nlabels, int64_t B, int L,
+                    const int32_t* ids, const int32_t* types, const int32_t* mask, float* out, int nthreads)
+{
+    const int H = c->hidden_size;
+    if (L <= 0 || L > c->max_position_embeddings || H % c->num_attention_heads || nlabels < 1) return -1;
+    for (int64_t i = 0; i < B * L; ++i) {
+        if (ids[i] < 0 || ids[i] >= c->vocab_size) return -1;
+        if (types && (types[i] < 0 || types[i] >= c->type_vocab_size)) return -1;
+    }
+    const float *Wp = head, *bp = Wp + (size_t)H * H, *Wc = bp + H, *bc = Wc + (size_t)nlabels * H;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int64_t b = 0; b < B; ++b) {
+        float* cls = (float*)malloc((size_t)2 * H * sizeof(float));
+        float* pooled = cls + H;
+        encode_one(c, blob, ids + b * L, types ? types + b * L : NULL, mask + b * L, L, NULL, NULL, NULL, cls);
+        for (int o = 0; o < H; ++o) {
+            float s = 0;
+            for (int j = 0; j < H; ++j) s += Wp[(size_t)o * H + j] * cls[j];
+            pooled[o] = tanhf(s + bp[o]);
+        }
+        for (int o = 0; o < nlabels; ++o) {
+            float s = 0;
+            for (int j = 0; j < H; ++j) s += Wc[(size_t)o * H + j] * pooled[j];
+            out[b * nlabels + o] = s + bc[o];
+        }
+        free(cls);
+    }
     return 0;
 }
 
@@ -207,6 +250,6 @@ int oracle_encode_taps(const oracle_bert_config* c, const float* blob, int L, co
 {
     if (L <= 0 || L > c->max_position_embeddings) return -1;
     for (int i = 0; i < L; ++i) if (ids[i] < 0 || ids[i] >= c->vocab_size) return -1;
-    encode_one(c, blob, ids, mask, L, out, tap_emb, tap_layers);
+    encode_one(c, blob, ids, NULL, mask, L, out, tap_emb, tap_layers, NULL);
     return 0;
 }

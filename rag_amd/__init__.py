@@ -10,7 +10,7 @@ from .documents import Document  # noqa: F401
 from .index import FlatIndex  # noqa: F401
 from .vectorstores import FAISS, MI355VectorStore, VectorStoreRetriever  # noqa: F401
 from .embeddings import HuggingFaceEmbeddings, MI355Embeddings  # noqa: F401
-from .retrievers import BM25Retriever, EnsembleRetriever  # noqa: F401
+from .retrievers import BM25Retriever, CrossEncoderReranker, EnsembleRetriever  # noqa: F401
 
 __all__ = ["Document", "FlatIndex", "FAISS", "MI355VectorStore", "VectorStoreRetriever",
-           "HuggingFaceEmbeddings", "MI355Embeddings", "MI355Error", "BM25Retriever", "EnsembleRetriever"]
+           "HuggingFaceEmbeddings", "MI355Embeddings", "MI355Error", "BM25Retriever", "EnsembleRetriever", "CrossEncoderReranker"]

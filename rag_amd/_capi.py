@@ -66,11 +66,18 @@ SYMBOLS = {
     "mi_index_stats": (_i32, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "mi_index_last_scan_time": (_i32, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mi_topk_merge_dev": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "mi_topk_packed_layout": (_i32, [_i64, _i32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    "mi_topk_merge_packed_dev": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "mi_encoder_blob_elems": (_i64, [_cfgp]),
     "mi_encoder_create": (_i32, [_vp, _cfgp, _vp, ctypes.c_size_t, _pp]),
     "mi_encoder_destroy": (None, [_vp]),
     "mi_encoder_encode": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "mi_encoder_encode_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "mi_encoder_encode_ragged": (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _vp]),
+    "mi_encoder_set_head": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32]),
+    "mi_encoder_classify": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "mi_encoder_classify_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mi_encoder_stats": (_i32, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "mi_encoder_last_time": (_i32, [_vp, ctypes.POINTER(ctypes.c_float)]),
 }
 
@@ -105,6 +112,15 @@ def load():
 def check(rc: int) -> None:
     if rc != MI_OK:
         raise MI355Error(rc, load().mi_last_error().decode("utf-8", "replace"))
+
+
+def stream_arg(device=None) -> ctypes.c_void_p:
+    """The `stream` argument of a *_dev entry point for PyTorch's current stream on `device`.  PyTorch's default
+    stream has handle 0, which the C-ABI reads as "the ctx's own stream" (non-blocking: it would not wait for the
+    tensors' producers, nor would their consumers wait for it): pass MI_STREAM_LEGACY for it."""
+    import torch
+    h = torch.cuda.current_stream(device).cuda_stream
+    return ctypes.c_void_p(h if h else 1)
 
 
 _ctx_cache: dict = {}

@@ -26,6 +26,9 @@ struct mi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
+    // ping-pong scratch of mi_topk_merge_dev for more than 4096 entries per query (grow-only, under mu)
+    void* merge_buf[2] = {nullptr, nullptr};
+    size_t merge_cap[2] = {0, 0};
 };
 
 int mi_ctx_device(mi_ctx* ctx) { return ctx->device; }
@@ -71,6 +74,7 @@ struct mi_index {
     // recorded behind every add on the stream that carried it; a search on another stream waits on it
     hipEvent_t ev_data = nullptr;
     // search workspace (grow-only)
+    DevBuf stage;               // host-buffer adds and get_rows go through it (grow-only, <= one 256-MB slab)
     DevBuf q_in, q_canon, q_bf16, qq, dense, pair_s, pair_i, lists, cnts, thrs, gthr, fail, part_s, part_i, sub_q, sub_qq, sub_s, sub_i, out_s, out_i;
     // stats
     int64_t st_queries = 0, st_fast = 0, st_exact = 0, st_rows = 0;
@@ -91,12 +95,6 @@ static int ensure_pin(mi_index* x)
     if (e != hipSuccess) { x->pin = nullptr; mi_set_error("hipHostMalloc failed: %s", hipGetErrorString(e)); return MI_ERR_OOM; }
     return MI_OK;
 }
-
-struct DeviceGuard {
-    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); want = dev; }
-    ~DeviceGuard() { if (prev != want && prev >= 0) (void)hipSetDevice(prev); }
-    int prev = -1, want = -1;
-};
 
 // ---------------------------------------------------------------- context
 extern "C" int mi_init(int device_id, mi_ctx** out)
@@ -131,6 +129,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* ctx)
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
+    for (void* b : ctx->merge_buf) if (b) (void)hipFree(b);
     delete ctx;
 }
 
@@ -179,7 +178,7 @@ extern "C" void mi_index_destroy(mi_index* idx)
     if (idx->max_xx) (void)hipFree(idx->max_xx);
     DevBuf* bufs[] = {&idx->q_in, &idx->q_canon, &idx->q_bf16, &idx->qq, &idx->dense, &idx->pair_s, &idx->pair_i,
                       &idx->lists, &idx->cnts, &idx->thrs, &idx->gthr, &idx->fail, &idx->part_s, &idx->part_i, &idx->sub_q, &idx->sub_qq,
-                      &idx->sub_s, &idx->sub_i, &idx->out_s, &idx->out_i, &idx->shadow};
+                      &idx->sub_s, &idx->sub_i, &idx->out_s, &idx->out_i, &idx->shadow, &idx->stage};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t ev : idx->ev_pool) (void)hipEventDestroy(ev);
     if (idx->ev_data) (void)hipEventDestroy(idx->ev_data);
@@ -201,11 +200,21 @@ static int index_reserve_locked(mi_index* x, int64_t rows_total)
     if (e != hipSuccess) { mi_set_error("index: hipMalloc(%zu) for rows failed: %s", (size_t)rows_total * row_bytes, hipGetErrorString(e)); return MI_ERR_OOM; }
     e = hipMalloc((void**)&nxx, (size_t)(rows_total + MI_ROW_SLACK) * sizeof(float));
     if (e != hipSuccess) { (void)hipFree(nrows); mi_set_error("index: hipMalloc for norms failed: %s", hipGetErrorString(e)); return MI_ERR_OOM; }
+    // An earlier mi_index_add_dev on a caller's stream may still be writing the old rows: the copy waits for
+    // the event recorded behind it (every add chains onto that event, so it covers all of them).  The
+    // synchronise below then makes the new buffers complete before any stream can be handed them.
+    hipError_t ce = hipSuccess;
     if (x->n > 0) {
-        MI_HIP(hipMemcpyAsync(nrows, x->rows, (size_t)x->n * row_bytes, hipMemcpyDeviceToDevice, st));
-        MI_HIP(hipMemcpyAsync(nxx, x->xx, (size_t)x->n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        ce = hipStreamWaitEvent(st, x->ev_data, 0);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(nrows, x->rows, (size_t)x->n * row_bytes, hipMemcpyDeviceToDevice, st);
+        if (ce == hipSuccess) ce = hipMemcpyAsync(nxx, x->xx, (size_t)x->n * sizeof(float), hipMemcpyDeviceToDevice, st);
     }
-    MI_HIP(hipStreamSynchronize(st));
+    if (ce == hipSuccess) ce = hipStreamSynchronize(st);
+    if (ce != hipSuccess) {
+        (void)hipFree(nrows); (void)hipFree(nxx);
+        mi_set_error("index: regrow copy failed: %s", hipGetErrorString(ce));
+        return MI_ERR_HIP;
+    }
     if (x->rows) (void)hipFree(x->rows);
     if (x->xx) (void)hipFree(x->xx);
     x->rows = nrows; x->xx = nxx; x->cap_rows = rows_total;
@@ -231,15 +240,13 @@ static int grow_for(mi_index* x, int64_t add)
 
 static inline void* row_ptr(mi_index* x, int64_t r) { return (char*)x->rows + (size_t)r * x->d_pad * x->elem(); }
 
-extern "C" int mi_index_add_dev(mi_index* idx, int64_t n, const void* x_dev, int src_dtype, void* stream)
+// Caller holds idx->mu and has set the device.
+static int add_dev_locked(mi_index* idx, int64_t n, const void* x_dev, int src_dtype, hipStream_t st)
 {
-    MI_REQUIRE(idx && n >= 0 && (x_dev || n == 0), "mi_index_add_dev: bad argument");
-    MI_REQUIRE(src_dtype == MI_DTYPE_F32 || src_dtype == MI_DTYPE_BF16, "mi_index_add_dev: unknown src dtype");
-    if (n == 0) return MI_OK;
-    std::lock_guard<std::mutex> lk(idx->mu);
-    DeviceGuard g(idx->ctx->device);
-    hipStream_t st = stream ? (hipStream_t)stream : idx->ctx->stream;
     MI_TRY(grow_for(idx, n));
+    // adds may arrive on different streams: this one runs behind every earlier one, so the event recorded at
+    // its end covers them all (a search waits on that one event)
+    if (idx->n > 0) MI_HIP(hipStreamWaitEvent(st, idx->ev_data, 0));
     MI_TRY(mi_launch_ingest(st, x_dev, src_dtype, idx->d, n, idx->d, idx->d_pad, idx->dtype, row_ptr(idx, idx->n)));
     MI_TRY(mi_launch_row_norms(st, row_ptr(idx, idx->n), idx->dtype, n, idx->d_pad, idx->xx + idx->n, idx->max_xx));
     MI_HIP(hipEventRecord(idx->ev_data, st));
@@ -247,27 +254,35 @@ extern "C" int mi_index_add_dev(mi_index* idx, int64_t n, const void* x_dev, int
     return MI_OK;
 }
 
+extern "C" int mi_index_add_dev(mi_index* idx, int64_t n, const void* x_dev, int src_dtype, void* stream)
+{
+    MI_REQUIRE(idx && n >= 0 && (x_dev || n == 0), "mi_index_add_dev: bad argument");
+    MI_REQUIRE(src_dtype == MI_DTYPE_F32 || src_dtype == MI_DTYPE_BF16, "mi_index_add_dev: unknown src dtype");
+    if (n == 0) return MI_OK;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    DeviceGuard g(idx->ctx->device);
+    return add_dev_locked(idx, n, x_dev, src_dtype, mi_pick_stream(stream, idx->ctx->stream));
+}
+
 extern "C" int mi_index_add(mi_index* idx, int64_t n, const float* x_host)
 {
     MI_REQUIRE(idx && n >= 0 && (x_host || n == 0), "mi_index_add: bad argument");
     if (n == 0) return MI_OK;
+    // one lock for the whole call: the rows of two concurrent adds never interleave
+    std::lock_guard<std::mutex> lk(idx->mu);
     DeviceGuard g(idx->ctx->device);
     hipStream_t st = idx->ctx->stream;
     // stage through a device buffer in slabs (bounded extra memory for huge adds)
     const int64_t slab = (int64_t)((256ull << 20) / ((size_t)idx->d * 4)) > 0 ? (int64_t)((256ull << 20) / ((size_t)idx->d * 4)) : 1;
-    void* stage = nullptr;
     const int64_t first = n < slab ? n : slab;
-    MI_HIP(hipMalloc(&stage, (size_t)first * idx->d * 4));
-    int rc = MI_OK;
-    for (int64_t off = 0; off < n && rc == MI_OK; off += slab) {
+    MI_TRY(idx->stage.ensure((size_t)first * idx->d * 4));
+    for (int64_t off = 0; off < n; off += slab) {
         const int64_t m = (n - off < slab) ? n - off : slab;
-        hipError_t e = hipMemcpyAsync(stage, x_host + off * idx->d, (size_t)m * idx->d * 4, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) { mi_set_error("mi_index_add: H2D copy failed: %s", hipGetErrorString(e)); rc = MI_ERR_HIP; break; }
-        rc = mi_index_add_dev(idx, m, stage, MI_DTYPE_F32, st);
-        if (rc == MI_OK && hipStreamSynchronize(st) != hipSuccess) { mi_set_error("mi_index_add: sync failed"); rc = MI_ERR_HIP; }
+        MI_HIP(hipMemcpyAsync(idx->stage.p, x_host + off * idx->d, (size_t)m * idx->d * 4, hipMemcpyHostToDevice, st));
+        MI_TRY(add_dev_locked(idx, m, idx->stage.p, MI_DTYPE_F32, st));
+        MI_HIP(hipStreamSynchronize(st));          // the slab is reused; the caller's buffer is free on return
     }
-    (void)hipFree(stage);
-    return rc;
+    return MI_OK;
 }
 
 extern "C" int mi_index_add_synthetic(mi_index* idx, int64_t n, uint64_t seed, int normalize)
@@ -296,12 +311,14 @@ extern "C" int mi_index_dim(const mi_index* idx) { return idx ? idx->d : -1; }
 extern "C" int mi_index_set_id_base(mi_index* idx, int64_t id_base)
 {
     MI_REQUIRE(idx && id_base >= 0, "mi_index_set_id_base: bad argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
     idx->id_base = id_base;
     return MI_OK;
 }
 extern "C" int mi_index_set_mode(mi_index* idx, int mode)
 {
     MI_REQUIRE(idx && mode >= MI_MODE_AUTO && mode <= MI_MODE_FAST, "mi_index_set_mode: bad argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
     idx->mode = mode;
     return MI_OK;
 }
@@ -319,27 +336,29 @@ extern "C" int mi_index_reset(mi_index* idx)
 
 extern "C" int mi_index_get_rows(mi_index* idx, int64_t row0, int64_t n, float* out_host)
 {
-    MI_REQUIRE(idx && out_host && row0 >= 0 && n >= 0 && row0 + n <= idx->n, "mi_index_get_rows: range [%lld,%lld) outside [0,%lld)",
-               (long long)row0, (long long)(row0 + n), (long long)(idx ? idx->n : 0));
-    if (n == 0) return MI_OK;
+    MI_REQUIRE(idx && out_host && row0 >= 0 && n >= 0, "mi_index_get_rows: bad argument");
     std::lock_guard<std::mutex> lk(idx->mu);
+    MI_REQUIRE(row0 + n <= idx->n, "mi_index_get_rows: range [%lld,%lld) outside [0,%lld)",
+               (long long)row0, (long long)(row0 + n), (long long)idx->n);
+    if (n == 0) return MI_OK;
     DeviceGuard g(idx->ctx->device);
     hipStream_t st = idx->ctx->stream;
-    float* tmp = nullptr;
-    MI_HIP(hipMalloc((void**)&tmp, (size_t)n * idx->d * 4));
-    int rc = mi_launch_export_rows(st, row_ptr(idx, row0), idx->dtype, n, idx->d, idx->d_pad, tmp);
-    if (rc == MI_OK) {
-        hipError_t e = hipMemcpyAsync(out_host, tmp, (size_t)n * idx->d * 4, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { mi_set_error("mi_index_get_rows: copy failed: %s", hipGetErrorString(e)); rc = MI_ERR_HIP; }
+    MI_HIP(hipStreamWaitEvent(st, idx->ev_data, 0));           // rows added on another stream
+    const int64_t slab = (int64_t)((256ull << 20) / ((size_t)idx->d * 4)) > 0 ? (int64_t)((256ull << 20) / ((size_t)idx->d * 4)) : 1;
+    MI_TRY(idx->stage.ensure((size_t)(n < slab ? n : slab) * idx->d * 4));
+    for (int64_t off = 0; off < n; off += slab) {
+        const int64_t m = (n - off < slab) ? n - off : slab;
+        MI_TRY(mi_launch_export_rows(st, row_ptr(idx, row0 + off), idx->dtype, m, idx->d, idx->d_pad, idx->stage.as<float>()));
+        MI_HIP(hipMemcpyAsync(out_host + off * idx->d, idx->stage.p, (size_t)m * idx->d * 4, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipStreamSynchronize(st));
     }
-    (void)hipFree(tmp);
-    return rc;
+    return MI_OK;
 }
 
 extern "C" int mi_index_stats(const mi_index* idx, int64_t out[4])
 {
     MI_REQUIRE(idx && out, "mi_index_stats: NULL argument");
+    std::lock_guard<std::mutex> lk(const_cast<mi_index*>(idx)->mu);
     out[0] = idx->st_queries; out[1] = idx->st_fast; out[2] = idx->st_exact; out[3] = idx->st_rows;
     return MI_OK;
 }
@@ -592,7 +611,7 @@ extern "C" int mi_index_search_dev(mi_index* idx, int64_t nq, const float* q_dev
     MI_REQUIRE(idx && (nq == 0 || (q_dev && out_scores_dev && out_ids_dev)), "mi_index_search_dev: NULL argument");
     std::lock_guard<std::mutex> lk(idx->mu);
     DeviceGuard g(idx->ctx->device);
-    hipStream_t st = stream ? (hipStream_t)stream : idx->ctx->stream;
+    hipStream_t st = mi_pick_stream(stream, idx->ctx->stream);
     return search_dev_locked(idx, nq, q_dev, k, out_scores_dev, out_ids_dev, st);
 }
 
@@ -633,17 +652,104 @@ extern "C" int mi_index_search(mi_index* idx, int64_t nq, const float* q_host, i
 }
 
 // ---------------------------------------------------------------- merge of per-shard lists
+// Up to MI_MERGE_CHUNK entries per query fit one merge_kernel workgroup.  Longer inputs (8 ranks x k = 2048) are
+// merged in passes: every chunk of MI_MERGE_CHUNK entries keeps its k best (k <= MI_MAX_K = half a chunk, so a pass
+// at least halves the list), until one chunk is left.  The intermediate lists live in two grow-only buffers of the
+// ctx; queries are taken in groups so those stay below ~128 MB each.
+#define MI_MERGE_CHUNK 4096
+static int merge_scratch(mi_ctx* ctx, int which, size_t bytes, hipStream_t st)
+{
+    if (bytes <= ctx->merge_cap[which]) return MI_OK;
+    if (ctx->merge_buf[which]) { MI_HIP(hipStreamSynchronize(st)); (void)hipFree(ctx->merge_buf[which]); ctx->merge_buf[which] = nullptr; ctx->merge_cap[which] = 0; }
+    hipError_t e = hipMalloc(&ctx->merge_buf[which], bytes);
+    if (e != hipSuccess) { ctx->merge_buf[which] = nullptr; mi_set_error("merge: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return MI_ERR_OOM; }
+    ctx->merge_cap[which] = bytes;
+    return MI_OK;
+}
+
+// Layout of the first pass's input (see merge_kernel).
+struct MergeIn { const float* s; const int64_t* i; int k_in; int64_t lstride_s, lstride_i, qstride; int64_t q_step_s, q_step_i; };
+
+static int merge_any(mi_ctx* ctx, hipStream_t st, int metric, int64_t nq, int64_t m, const MergeIn& in,
+                     int k, float* out_s, int64_t* out_i)
+{
+    if (m <= MI_MERGE_CHUNK)
+        return mi_launch_merge_ex(st, metric, nq, (int)m, (int)m, in.s, in.i, in.k_in, in.lstride_s, in.lstride_i, in.qstride, k, out_s, out_i, k);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const int64_t m1 = (m + MI_MERGE_CHUNK - 1) / MI_MERGE_CHUNK * k;           // entries per query after the first pass
+    int64_t qg = ((int64_t)128 << 20) / (m1 * 12);
+    if (qg < 1) qg = 1;
+    if (qg > nq) qg = nq;
+    const size_t s_bytes = ((size_t)qg * m1 * sizeof(float) + 255) & ~(size_t)255;
+    MI_TRY(merge_scratch(ctx, 0, s_bytes + (size_t)qg * m1 * sizeof(int64_t), st));
+    MI_TRY(merge_scratch(ctx, 1, s_bytes + (size_t)qg * m1 * sizeof(int64_t), st));   // pass 2 writes at most half of it
+    for (int64_t q0 = 0; q0 < nq; q0 += qg) {
+        const int64_t qc = (nq - q0 < qg) ? nq - q0 : qg;
+        const float* cs = in.s + q0 * in.q_step_s;
+        const int64_t* ci = in.i + q0 * in.q_step_i;
+        int ck = in.k_in;
+        int64_t cm = m, cls = in.lstride_s, cli = in.lstride_i, cq = in.qstride;
+        int which = 0;
+        while (cm > MI_MERGE_CHUNK) {
+            const int64_t nch = (cm + MI_MERGE_CHUNK - 1) / MI_MERGE_CHUNK;
+            float* os = reinterpret_cast<float*>(ctx->merge_buf[which]);
+            int64_t* oi = reinterpret_cast<int64_t*>(static_cast<char*>(ctx->merge_buf[which]) + s_bytes);
+            MI_TRY(mi_launch_merge_ex(st, metric, qc, (int)cm, MI_MERGE_CHUNK, cs, ci, ck, cls, cli, cq, k, os, oi, nch * k));
+            cs = os; ci = oi; cm = nch * k; ck = (int)cm; cls = 0; cli = 0; cq = cm;
+            which ^= 1;
+        }
+        MI_TRY(mi_launch_merge_ex(st, metric, qc, (int)cm, (int)cm, cs, ci, ck, cls, cli, cq, k, out_s + q0 * k, out_i + q0 * k, k));
+    }
+    return MI_OK;
+}
+
 extern "C" int mi_topk_merge_dev(mi_ctx* ctx, int metric, int64_t nq, int nlists, int k_in,
                                  const float* in_scores_dev, const int64_t* in_ids_dev,
                                  int k, float* out_scores_dev, int64_t* out_ids_dev, void* stream)
 {
     MI_REQUIRE(ctx && nq >= 0 && nlists >= 1 && k_in >= 1 && k >= 1, "mi_topk_merge_dev: bad argument");
     MI_REQUIRE(metric == MI_METRIC_IP || metric == MI_METRIC_L2, "mi_topk_merge_dev: unknown metric");
+    if (k > MI_MAX_K) { mi_set_error("mi_topk_merge_dev: k=%d exceeds MI_MAX_K=%d", k, MI_MAX_K); return MI_ERR_UNSUPPORTED; }
     if (nq == 0) return MI_OK;
     MI_REQUIRE(in_scores_dev && in_ids_dev && out_scores_dev && out_ids_dev, "mi_topk_merge_dev: NULL buffer");
     const int64_t m = (int64_t)nlists * k_in;
-    if (m > 4096) { mi_set_error("mi_topk_merge_dev: nlists*k_in = %lld exceeds 4096", (long long)m); return MI_ERR_UNSUPPORTED; }
+    MI_REQUIRE(m < ((int64_t)1 << 24), "mi_topk_merge_dev: nlists*k_in = %lld is out of range", (long long)m);
     DeviceGuard g(ctx->device);
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    return mi_launch_merge(st, metric, nq, (int)m, in_scores_dev, in_ids_dev, m, k, out_scores_dev, out_ids_dev, k);
+    hipStream_t st = mi_pick_stream(stream, ctx->stream);
+    const MergeIn in{in_scores_dev, in_ids_dev, (int)m, 0, 0, m, m, m};
+    return merge_any(ctx, st, metric, nq, m, in, k, out_scores_dev, out_ids_dev);
+}
+
+// ---------------------------------------------------------------- packed per-rank lists (the all-gather's message)
+// One block per rank: [nq][k] fp32 scores, then (8-byte aligned) [nq][k] int64 ids.  A rank's local search writes
+// its block in place (mi_index_search_dev with pointers into it), ONE all-gather of block_bytes per rank leaves the
+// blocks rank-major, and the merge reads that layout directly.
+extern "C" int mi_topk_packed_layout(int64_t nq, int k, size_t* ids_offset, size_t* block_bytes)
+{
+    MI_REQUIRE(nq >= 0 && k >= 1 && ids_offset && block_bytes, "mi_topk_packed_layout: bad argument");
+    const size_t off = ((size_t)nq * k * sizeof(float) + 255) & ~(size_t)255;
+    *ids_offset = off;
+    *block_bytes = (off + (size_t)nq * k * sizeof(int64_t) + 255) & ~(size_t)255;
+    return MI_OK;
+}
+
+extern "C" int mi_topk_merge_packed_dev(mi_ctx* ctx, int metric, int64_t nq, int nlists, int k_in, const void* packed_dev,
+                                        int k, float* out_scores_dev, int64_t* out_ids_dev, void* stream)
+{
+    MI_REQUIRE(ctx && nq >= 0 && nlists >= 1 && k_in >= 1 && k >= 1, "mi_topk_merge_packed_dev: bad argument");
+    MI_REQUIRE(metric == MI_METRIC_IP || metric == MI_METRIC_L2, "mi_topk_merge_packed_dev: unknown metric");
+    if (k > MI_MAX_K) { mi_set_error("mi_topk_merge_packed_dev: k=%d exceeds MI_MAX_K=%d", k, MI_MAX_K); return MI_ERR_UNSUPPORTED; }
+    if (nq == 0) return MI_OK;
+    MI_REQUIRE(packed_dev && out_scores_dev && out_ids_dev, "mi_topk_merge_packed_dev: NULL buffer");
+    MI_REQUIRE(((uintptr_t)packed_dev & 7) == 0, "mi_topk_merge_packed_dev: the packed buffer must be 8-byte aligned");
+    const int64_t m = (int64_t)nlists * k_in;
+    MI_REQUIRE(m < ((int64_t)1 << 24), "mi_topk_merge_packed_dev: nlists*k_in = %lld is out of range", (long long)m);
+    size_t ids_off = 0, block = 0;
+    MI_TRY(mi_topk_packed_layout(nq, k_in, &ids_off, &block));
+    DeviceGuard g(ctx->device);
+    hipStream_t st = mi_pick_stream(stream, ctx->stream);
+    const char* base = static_cast<const char*>(packed_dev);
+    const MergeIn in{reinterpret_cast<const float*>(base), reinterpret_cast<const int64_t*>(base + ids_off), k_in,
+                     (int64_t)(block / sizeof(float)), (int64_t)(block / sizeof(int64_t)), k_in, k_in, k_in};
+    return merge_any(ctx, st, metric, nq, m, in, k, out_scores_dev, out_ids_dev);
 }

@@ -76,6 +76,27 @@ __host__ __device__ inline float mi_bf16_to_f32(uint16_t h) {
     return __builtin_bit_cast(float, (uint32_t)h << 16);
 }
 
+// Selects a device for the current host thread for the lifetime of the object (entry points are
+// called from arbitrary threads and set their ctx's device themselves).
+struct DeviceGuard {
+    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); want = dev; }
+    ~DeviceGuard() { if (prev != want && prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+    int prev = -1, want = -1;
+};
+
+// The `stream` argument of the *_dev entry points (include/mi355rag.h): NULL = the ctx's own stream,
+// MI_STREAM_LEGACY ((void*)1, the value of hipStreamLegacy) = the legacy default ("null") stream, anything
+// else a hipStream_t.  A caller whose work sits on the null stream (PyTorch's default stream has handle 0)
+// must not pass 0: that selects the ctx stream, which is non-blocking and would not wait for it.
+static inline hipStream_t mi_pick_stream(void* s, hipStream_t own)
+{
+    if (s == nullptr) return own;
+    if (s == MI_STREAM_LEGACY) return (hipStream_t) nullptr;
+    return (hipStream_t)s;
+}
+
 static inline int64_t mi_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int mi_next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 

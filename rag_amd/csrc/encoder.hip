@@ -26,6 +26,8 @@
 // (BASELINE.json north_star), measured ~5e-6 in tests/test_encoder_gpu.py.
 #include <float.h>
 #include <stdlib.h>
+#include <string.h>
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 #include <mutex>
@@ -100,8 +102,9 @@ __device__ __forceinline__ float wave_sum(float v)
 // ---------------------------------------------------------------- embeddings + LayerNorm
 // One wave per token; lane holds columns lane, lane+64, ... (H <= 1024).
 template <int NCH>
-__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, int64_t T, int L, int H, int vocab,
-        const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type0,
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ type_ids,
+        int ntypes, int64_t T, int L, int H, int vocab,
+        const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type_tab,
         const float* __restrict__ gamma, const float* __restrict__ beta, float eps, uint16_t* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
@@ -109,6 +112,10 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
     if (tok >= T) return;
     int id = ids[tok];
     if (id < 0 || id >= vocab) id = 0;              // ids are validated on the host; never index out of the table
+    // token type: 0 for a bi-encoder (type_ids == nullptr); the segment id of a cross-encoder pair otherwise
+    int tt = type_ids ? type_ids[tok] : 0;
+    if (tt < 0 || tt >= ntypes) tt = 0;
+    const float* const type0 = type_tab + (int64_t)tt * H;
     const int p = (int)(tok % L);
     float x[NCH][8];
     float s = 0.0f;
@@ -1369,12 +1376,58 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = mi_f32_to_bf16(in[i]);
 }
 
+
+// ---------------------------------------------------------------- cross-encoder head
+// BertPooler + classifier (modeling_bert.py BertPooler: tanh(W_p h[CLS] + b_p); BertForSequenceClassification:
+// logits = W_c pooled + b_c; dropout is the identity at inference).  One workgroup per sequence, fp32 throughout;
+// an output is one wave's dot product (lanes over the hidden columns, coalesced rows of W).
+__global__ __launch_bounds__(256) void cls_head_kernel(const uint16_t* __restrict__ hid, int L, int H,
+        const float* __restrict__ Wp, const float* __restrict__ bp, const float* __restrict__ Wc, const float* __restrict__ bc,
+        int nlabels, float* __restrict__ out)
+{
+    __shared__ float x[1024], pooled[1024];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t b = blockIdx.x;
+    const uint16_t* row = hid + b * L * (int64_t)H;              // the [CLS] token is position 0
+    for (int c = t; c < H; c += 256) x[c] = bf2f(row[c]);
+    __syncthreads();
+    for (int o = wave; o < H; o += 4) {
+        float s = 0.0f;
+        for (int c = lane; c < H; c += 64) s += Wp[(int64_t)o * H + c] * x[c];
+        s = wave_sum(s);
+        if (lane == 0) pooled[o] = tanhf(s + bp[o]);
+    }
+    __syncthreads();
+    for (int j = wave; j < nlabels; j += 4) {
+        float s = 0.0f;
+        for (int c = lane; c < H; c += 64) s += Wc[(int64_t)j * H + c] * pooled[c];
+        s = wave_sum(s);
+        if (lane == 0) out[b * nlabels + j] = s + bc[j];
+    }
+}
+
 // ================================================================ host side
 struct LayerW {
     uint16_t *Wqkv, *Wo, *Wi, *Wd;                 // bf16 [out][in]
     uint16_t *Wi_p = nullptr;                      // [I / 32][12][32][32] swizzled LDS image of Wi blocks (ffn_ln_kernel)
     uint16_t *Wo_p = nullptr, *Wd_p = nullptr;     // the same, [in / 32][out][32]: a 32-k stage of gemm_ln_kernel is one contiguous block
     float *bqkv, *bo, *bi, *bd, *g1, *b1, *g2, *b2; // fp32
+};
+
+// grow-only pinned host block
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return MI_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; mi_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return MI_ERR_OOM; }
+        cap = bytes;
+        return MI_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
 struct mi_encoder {
@@ -1389,11 +1442,20 @@ struct mi_encoder {
     // workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    int32_t *d_ids = nullptr, *d_mask = nullptr;
+    // device staging of the host-pointer entry points: ids | types | mask, and the outputs
+    int32_t* d_io = nullptr;
     float* d_out = nullptr;
     size_t io_cap = 0, out_cap = 0;
+    // pinned host staging: two sets, so the host fills one while the GPU reads the other
+    PinBuf pin_io[2], pin_out[2];
+    hipEvent_t ev_pin[2] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // cross-encoder head (mi_encoder_set_head): pooler W[H][H] b[H], classifier W[nl][H] b[nl], fp32 on device
+    float* head = nullptr;
+    int nlabels = 0;
+    // counters since creation: sequences, padded tokens, passes on the bulk / on the latency kernel family
+    int64_t st_seqs = 0, st_tokens = 0, st_bulk = 0, st_latency = 0;
 };
 
 extern "C" int64_t mi_encoder_blob_elems(const mi_bert_config* c)
@@ -1408,12 +1470,14 @@ extern "C" int64_t mi_encoder_blob_elems(const mi_bert_config* c)
 static void encoder_free(mi_encoder* e)
 {
     if (!e) return;
+    for (LayerW& lw : e->layers) if (lw.bqkv) (void)hipFree(lw.bqkv);
     if (e->blob) (void)hipFree(e->blob);
     if (e->wbf) (void)hipFree(e->wbf);
     if (e->ws) (void)hipFree(e->ws);
-    if (e->d_ids) (void)hipFree(e->d_ids);
-    if (e->d_mask) (void)hipFree(e->d_mask);
+    if (e->d_io) (void)hipFree(e->d_io);
     if (e->d_out) (void)hipFree(e->d_out);
+    if (e->head) (void)hipFree(e->head);
+    for (int s = 0; s < 2; ++s) { e->pin_io[s].release(); e->pin_out[s].release(); if (e->ev_pin[s]) (void)hipEventDestroy(e->ev_pin[s]); }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     delete e;
@@ -1434,16 +1498,13 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
     MI_REQUIRE((int64_t)n_elems == want, "mi_encoder_create: blob has %zu elements, config needs %lld", n_elems, (long long)want);
 
     const int device = mi_ctx_device(ctx);
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    (void)hipSetDevice(device);
+    DeviceGuard guard(device);
     mi_encoder* e = new (std::nothrow) mi_encoder();
     if (!e) { mi_set_error("mi_encoder_create: out of host memory"); return MI_ERR_OOM; }
     e->device = device;
     e->stream = mi_ctx_stream(ctx);
     e->cfg = *cfg;
-    int rc = MI_OK;
-    auto fail = [&](int code) { encoder_free(e); if (prev >= 0) (void)hipSetDevice(prev); return code; };
+    auto fail = [&](int code) { encoder_free(e); return code; };
 #define ENC_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { mi_set_error("%s failed: %s", #call, hipGetErrorString(_e)); return fail(_e == hipErrorOutOfMemory ? MI_ERR_OOM : MI_ERR_HIP); } } while (0)
     ENC_HIP(hipMalloc((void**)&e->blob, (size_t)want * sizeof(float)));
     ENC_HIP(hipMemcpyAsync(e->blob, blob_host, (size_t)want * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -1451,6 +1512,7 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
     ENC_HIP(hipMalloc((void**)&e->wbf, (size_t)(per_layer_w * cfg->num_hidden_layers) * sizeof(uint16_t)));
     ENC_HIP(hipEventCreate(&e->ev0));
     ENC_HIP(hipEventCreate(&e->ev1));
+    for (int s = 0; s < 2; ++s) ENC_HIP(hipEventCreateWithFlags(&e->ev_pin[s], hipEventDisableTiming));
 
     float* p = e->blob;
     e->word = p; p += (int64_t)cfg->vocab_size * H;
@@ -1483,19 +1545,19 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
         lw.Wd_p = w; cvt_pack32_kernel<<<1024, 256, 0, e->stream>>>(Wd, w, H, I); w += (int64_t)H * I;
         lw.Wi_p = w; if (H == 384) cvt_pack_w1_kernel<<<1024, 256, 0, e->stream>>>(Wi, w, I); w += (int64_t)H * I;
         // fused qkv bias: bq|bk|bv are not contiguous in the blob -> a small packed copy
-        ENC_HIP(hipMalloc((void**)&lw.bqkv, (size_t)3 * H * sizeof(float)));
+        lw.bqkv = nullptr;
+        hipError_t me = hipMalloc((void**)&lw.bqkv, (size_t)3 * H * sizeof(float));
+        lw.bo = bo; lw.bi = bi; lw.bd = bd; lw.g1 = g1; lw.b1 = b1; lw.g2 = g2; lw.b2 = b2;
+        e->layers.push_back(lw);                       // owned by e from here on (encoder_free releases bqkv)
+        ENC_HIP(me);
         ENC_HIP(hipMemcpyAsync(lw.bqkv, bq, (size_t)H * 4, hipMemcpyDeviceToDevice, e->stream));
         ENC_HIP(hipMemcpyAsync(lw.bqkv + H, bk, (size_t)H * 4, hipMemcpyDeviceToDevice, e->stream));
         ENC_HIP(hipMemcpyAsync(lw.bqkv + 2 * H, bv, (size_t)H * 4, hipMemcpyDeviceToDevice, e->stream));
-        lw.bo = bo; lw.bi = bi; lw.bd = bd; lw.g1 = g1; lw.b1 = b1; lw.g2 = g2; lw.b2 = b2;
-        e->layers.push_back(lw);
     }
     ENC_HIP(hipGetLastError());
     ENC_HIP(hipStreamSynchronize(e->stream));
     ENC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
 #undef ENC_HIP
-    (void)rc;
-    if (prev >= 0) (void)hipSetDevice(prev);
     *out = e;
     return MI_OK;
 }
@@ -1503,13 +1565,32 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
 extern "C" void mi_encoder_destroy(mi_encoder* e)
 {
     if (!e) return;
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    (void)hipSetDevice(e->device);
+    DeviceGuard guard(e->device);
     (void)hipStreamSynchronize(e->stream);
-    for (LayerW& lw : e->layers) if (lw.bqkv) (void)hipFree(lw.bqkv);
     encoder_free(e);
-    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+// Cross-encoder head: pooler_w [H][H], pooler_b [H], cls_w [num_labels][H], cls_b [num_labels], host fp32.
+extern "C" int mi_encoder_set_head(mi_encoder* e, const float* pooler_w, const float* pooler_b,
+                                   const float* cls_w, const float* cls_b, int num_labels)
+{
+    MI_REQUIRE(e && pooler_w && pooler_b && cls_w && cls_b, "mi_encoder_set_head: NULL argument");
+    MI_REQUIRE(num_labels >= 1 && num_labels <= 64, "mi_encoder_set_head: num_labels %d outside [1, 64]", num_labels);
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard guard(e->device);
+    const size_t H = (size_t)e->cfg.hidden_size;
+    const size_t n = H * H + H + (size_t)num_labels * H + (size_t)num_labels;
+    MI_HIP(hipStreamSynchronize(e->stream));
+    if (e->head) { (void)hipFree(e->head); e->head = nullptr; e->nlabels = 0; }
+    MI_HIP(hipMalloc((void**)&e->head, n * sizeof(float)));
+    float* d = e->head;
+    MI_HIP(hipMemcpyAsync(d, pooler_w, H * H * 4, hipMemcpyHostToDevice, e->stream)); d += H * H;
+    MI_HIP(hipMemcpyAsync(d, pooler_b, H * 4, hipMemcpyHostToDevice, e->stream)); d += H;
+    MI_HIP(hipMemcpyAsync(d, cls_w, (size_t)num_labels * H * 4, hipMemcpyHostToDevice, e->stream)); d += (size_t)num_labels * H;
+    MI_HIP(hipMemcpyAsync(d, cls_b, (size_t)num_labels * 4, hipMemcpyHostToDevice, e->stream));
+    MI_HIP(hipStreamSynchronize(e->stream));
+    e->nlabels = num_labels;
+    return MI_OK;
 }
 
 // K = 384 projections on enough rows to fill the chip: the weight-stationary kernel
@@ -1562,27 +1643,55 @@ static bool launch_gemm(hipStream_t st, const uint16_t* A, const uint16_t* W, co
     return false;
 }
 
-// All device pointers; B*L tokens.  Caller holds the encoder mutex and has set the device.
-static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids, const int32_t* mask, float* out, hipStream_t st)
+// Bytes of activation workspace one pass over T tokens needs: h, tmp [T][H]; ctx [Tp][H]; qkv [Tp][3H]; mid [Tp][I] (bf16)
+// + 128 rows of slack: the weight-stationary GEMM streams whole 128-row tiles of its A operand.
+// ctx, qkv and mid may be written in the blocked [rows / 128][cols / 32][128][32] layout, which covers whole
+// 128-row tiles: each of them gets roundup(T, 128) rows, so a tile of one buffer never reaches into the next
+// (the attention kernel writes ctx while other workgroups still read qkv).
+static size_t encoder_ws_need(const mi_bert_config& c, int64_t T)
+{
+    const size_t H = (size_t)c.hidden_size, I = (size_t)c.intermediate_size;
+    const size_t Tp = ((size_t)T + 127) / 128 * 128;
+    return ((size_t)T * 2 * H + Tp * (H + 3 * H + I) + (size_t)128 * I) * sizeof(uint16_t);
+}
+
+// The encoder's own grow-only workspace, sized for a pass over T tokens.
+static int ensure_ws(mi_encoder* e, int64_t T, hipStream_t st)
+{
+    const size_t need = encoder_ws_need(e->cfg, T);
+    if (need <= e->ws_bytes) return MI_OK;
+    if (e->ws) { MI_HIP(hipStreamSynchronize(st)); (void)hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0; }
+    hipError_t er = hipMalloc(&e->ws, need);
+    if (er != hipSuccess) { e->ws = nullptr; mi_set_error("encode: hipMalloc(%zu) for the workspace failed: %s", need, hipGetErrorString(er)); return MI_ERR_OOM; }
+    e->ws_bytes = need;
+    return MI_OK;
+}
+
+// One pass: all device pointers, B*L tokens.  Caller holds the encoder mutex and has set the device.
+// types: token type ids or nullptr (all 0).  out_emb: pooled sentence embeddings [B][H], or nullptr;
+// out_logits: cross-encoder logits [B][nlabels], or nullptr.  ws_ext: caller-supplied workspace of ws_ext_bytes
+// (the allocation-free entry point), or nullptr: the encoder's own grow-only workspace.
+static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids, const int32_t* types, const int32_t* mask,
+                              float* out_emb, float* out_logits, hipStream_t st, void* ws_ext, size_t ws_ext_bytes)
 {
     const mi_bert_config& c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size, NH = c.num_attention_heads;
     const int64_t T = B * L;
     MI_REQUIRE(T < ((int64_t)1 << 31) / 16, "encode: too many tokens in one call (%lld)", (long long)T);
-    // workspace: h, tmp, ctx [T][H]; qkv [T][3H]; mid [T][I]  (bf16)
-    // + 128 rows of slack: the weight-stationary GEMM streams whole 128-row tiles of its A operand
-    // ctx, qkv and mid may be written in the blocked [rows / 128][cols / 32][128][32] layout, which covers whole
-    // 128-row tiles: each of them gets roundup(T, 128) rows, so a tile of one buffer never reaches into the next
-    // (the attention kernel writes ctx while other workgroups still read qkv).
-    const size_t Tp = ((size_t)T + 127) / 128 * 128;
-    const size_t need = ((size_t)T * 2 * H + Tp * ((size_t)H + 3 * H + I) + (size_t)128 * I) * sizeof(uint16_t);
-    if (need > e->ws_bytes) {
-        if (e->ws) { MI_HIP(hipStreamSynchronize(st)); (void)hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0; }
-        hipError_t er = hipMalloc(&e->ws, need);
-        if (er != hipSuccess) { mi_set_error("encode: hipMalloc(%zu) for the workspace failed: %s", need, hipGetErrorString(er)); return MI_ERR_OOM; }
-        e->ws_bytes = need;
+    const size_t need = encoder_ws_need(c, T);
+    void* wsp = nullptr;
+    if (ws_ext) {
+        if (need > ws_ext_bytes) {
+            mi_set_error("encode: %lld tokens need %zu bytes of workspace, the allocation-free entry point holds %zu", (long long)T, need, ws_ext_bytes);
+            return MI_ERR_UNSUPPORTED;
+        }
+        wsp = ws_ext;
+    } else {
+        MI_TRY(ensure_ws(e, T, st));
+        wsp = e->ws;
     }
-    uint16_t* h = (uint16_t*)e->ws;
+    const size_t Tp = ((size_t)T + 127) / 128 * 128;
+    uint16_t* h = (uint16_t*)wsp;
     uint16_t* tmp = h + (size_t)T * H;
     uint16_t* ctx = tmp + (size_t)T * H;
     uint16_t* qkv = ctx + Tp * H;
@@ -1611,8 +1720,8 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
     static const bool front_off = getenv("MI_FFN_FRONT") && atoi(getenv("MI_FFN_FRONT")) == 0;
     const bool fused_front = fused_ffn && !front_off;
     MI_HIP(hipEventRecord(e->ev0, st));
-    if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
-    else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
+    if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, types, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
+    else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, types, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     for (const LayerW& lw : e->layers) {
         const bool qkv_blocked = launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H, true);
         attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, scale_log2e, qkv_blocked ? 1 : 0, fused_ln ? 1 : 0);
@@ -1643,11 +1752,43 @@ static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids
             else add_ln_kernel<2><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g2, lw.b2, c.layer_norm_eps, h);
         }
     }
-    if (H <= 512) pool_kernel<1><<<(unsigned)B, 64 * POOL_WAVES, 0, st>>>(h, mask, L, H, c.normalize, out);
-    else pool_kernel<2><<<(unsigned)B, 64 * POOL_WAVES, 0, st>>>(h, mask, L, H, c.normalize, out);
+    if (out_emb) {
+        if (H <= 512) pool_kernel<1><<<(unsigned)B, 64 * POOL_WAVES, 0, st>>>(h, mask, L, H, c.normalize, out_emb);
+        else pool_kernel<2><<<(unsigned)B, 64 * POOL_WAVES, 0, st>>>(h, mask, L, H, c.normalize, out_emb);
+    }
+    if (out_logits) {
+        const float* hw = e->head;
+        const size_t HH = (size_t)H;
+        cls_head_kernel<<<(unsigned)B, 256, 0, st>>>(h, L, H, hw, hw + HH * HH, hw + HH * HH + HH, hw + HH * HH + HH + (size_t)e->nlabels * HH,
+                                                     e->nlabels, out_logits);
+    }
     MI_HIP(hipEventRecord(e->ev1, st));
     MI_HIP(hipGetLastError());
     e->timed = true;
+    e->st_seqs += B;
+    e->st_tokens += T;
+    if (bulk) e->st_bulk += 1; else e->st_latency += 1;
+    return MI_OK;
+}
+
+static int64_t encoder_pass_tokens()
+{
+    // bounded workspace: at most 64K tokens per pass
+    static const int64_t pass_tokens = getenv("MI_ENC_PASS_TOKENS") ? atoll(getenv("MI_ENC_PASS_TOKENS")) : 65536;
+    return pass_tokens > 0 ? pass_tokens : 65536;
+}
+
+// Device buffers [B][L] in passes of at most MI_ENC_PASS_TOKENS tokens.  Caller holds the mutex.
+static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids, const int32_t* types, const int32_t* mask,
+                             float* out_emb, float* out_logits, hipStream_t st)
+{
+    const int64_t bmax = (encoder_pass_tokens() / L) > 0 ? encoder_pass_tokens() / L : 1;
+    for (int64_t b0 = 0; b0 < B; b0 += bmax) {
+        const int64_t nb = (B - b0 < bmax) ? B - b0 : bmax;
+        MI_TRY(encode_pass_locked(e, nb, L, ids + b0 * L, types ? types + b0 * L : nullptr, mask + b0 * L,
+                                  out_emb ? out_emb + b0 * e->cfg.hidden_size : nullptr,
+                                  out_logits ? out_logits + b0 * e->nlabels : nullptr, st, nullptr, 0));
+    }
     return MI_OK;
 }
 
@@ -1659,20 +1800,102 @@ extern "C" int mi_encoder_encode_dev(mi_encoder* e, int64_t B, int L, const int3
     if (B == 0) return MI_OK;
     MI_REQUIRE(ids_dev && mask_dev && out_emb_dev, "mi_encoder_encode_dev: NULL buffer");
     std::lock_guard<std::mutex> lk(e->mu);
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    if (prev != e->device) (void)hipSetDevice(e->device);
-    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-    int rc = MI_OK;
-    // bounded workspace: at most 64K tokens per pass
-    static const int64_t pass_tokens = getenv("MI_ENC_PASS_TOKENS") ? atoll(getenv("MI_ENC_PASS_TOKENS")) : 65536;
-    const int64_t bmax = (pass_tokens / L) > 0 ? pass_tokens / L : 1;
-    for (int64_t b0 = 0; b0 < B && rc == MI_OK; b0 += bmax) {
-        const int64_t nb = (B - b0 < bmax) ? B - b0 : bmax;
-        rc = encode_dev_locked(e, nb, L, ids_dev + b0 * L, mask_dev + b0 * L, out_emb_dev + b0 * e->cfg.hidden_size, st);
+    DeviceGuard guard(e->device);
+    return encode_dev_locked(e, B, L, ids_dev, nullptr, mask_dev, out_emb_dev, nullptr, mi_pick_stream(stream, e->stream));
+}
+
+extern "C" int mi_encoder_classify_dev(mi_encoder* e, int64_t B, int L, const int32_t* ids_dev, const int32_t* type_ids_dev,
+                                       const int32_t* mask_dev, float* out_logits_dev, void* stream)
+{
+    MI_REQUIRE(e && B >= 0 && L > 0, "mi_encoder_classify_dev: bad argument");
+    MI_REQUIRE(L <= e->cfg.max_position_embeddings, "mi_encoder_classify_dev: L=%d exceeds max_position_embeddings=%d", L, e->cfg.max_position_embeddings);
+    if (B == 0) return MI_OK;
+    MI_REQUIRE(ids_dev && mask_dev && out_logits_dev, "mi_encoder_classify_dev: NULL buffer");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->head) { mi_set_error("mi_encoder_classify_dev: no classification head loaded (mi_encoder_set_head)"); return MI_ERR_INVALID_ARG; }
+    DeviceGuard guard(e->device);
+    return encode_dev_locked(e, B, L, ids_dev, type_ids_dev, mask_dev, nullptr, out_logits_dev, mi_pick_stream(stream, e->stream));
+}
+
+// Device staging of the host-pointer entry points (caller holds the mutex): room for three [tokens] int32 planes
+// and `out_bytes` of results.
+static int ensure_io(mi_encoder* e, size_t tokens, size_t out_bytes, hipStream_t st)
+{
+    const size_t nio = 3 * tokens * sizeof(int32_t);
+    if (nio > e->io_cap) {
+        MI_HIP(hipStreamSynchronize(st));
+        if (e->d_io) (void)hipFree(e->d_io);
+        e->d_io = nullptr; e->io_cap = 0;
+        hipError_t er = hipMalloc((void**)&e->d_io, nio);
+        if (er != hipSuccess) { e->d_io = nullptr; mi_set_error("encode: hipMalloc(%zu) failed: %s", nio, hipGetErrorString(er)); return MI_ERR_OOM; }
+        e->io_cap = nio;
     }
-    if (prev != e->device && prev >= 0) (void)hipSetDevice(prev);
-    return rc;
+    if (out_bytes > e->out_cap) {
+        MI_HIP(hipStreamSynchronize(st));
+        if (e->d_out) (void)hipFree(e->d_out);
+        e->d_out = nullptr; e->out_cap = 0;
+        hipError_t er = hipMalloc((void**)&e->d_out, out_bytes);
+        if (er != hipSuccess) { e->d_out = nullptr; mi_set_error("encode: hipMalloc(%zu) failed: %s", out_bytes, hipGetErrorString(er)); return MI_ERR_OOM; }
+        e->out_cap = out_bytes;
+    }
+    return MI_OK;
+}
+
+static int check_ids(const char* who, const mi_encoder* e, const int32_t* ids, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i)
+        if (ids[i] < 0 || ids[i] >= e->cfg.vocab_size) {
+            mi_set_error("%s: token id %d at position %lld outside [0,%d)", who, ids[i], (long long)i, e->cfg.vocab_size);
+            return MI_ERR_INVALID_ARG;
+        }
+    return MI_OK;
+}
+
+// Host [B][L] arrays in, host results out.  The mutex is held from the first staging copy to the last read-back:
+// the staging buffers and the stream are the encoder's, so two threads must not interleave on them.
+static int encode_host(mi_encoder* e, const char* who, int64_t B, int L, const int32_t* ids, const int32_t* types,
+                       const int32_t* mask, float* out, bool logits)
+{
+    MI_TRY(check_ids(who, e, ids, B * L));
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (logits && !e->head) { mi_set_error("%s: no classification head loaded (mi_encoder_set_head)", who); return MI_ERR_INVALID_ARG; }
+    DeviceGuard guard(e->device);
+    hipStream_t st = e->stream;
+    const size_t T = (size_t)B * L, nio = T * sizeof(int32_t);
+    const size_t width = logits ? (size_t)e->nlabels : (size_t)e->cfg.hidden_size;
+    const size_t nout = (size_t)B * width * sizeof(float);
+    MI_TRY(ensure_io(e, T, nout, st));
+    int32_t* d_ids = e->d_io;
+    int32_t* d_types = types ? e->d_io + T : nullptr;
+    int32_t* d_mask = e->d_io + 2 * T;
+    // small calls (a query, a few chunks) go through the pinned block: a pageable copy costs a staging hop and a
+    // sync inside the runtime each way
+    const bool pinned = 3 * nio <= ((size_t)1 << 20) && nout <= ((size_t)1 << 20);
+    if (pinned) {
+        MI_TRY(e->pin_io[0].ensure((size_t)1 << 20));
+        MI_TRY(e->pin_out[0].ensure((size_t)1 << 20));
+        char* pb = static_cast<char*>(e->pin_io[0].p);
+        memcpy(pb, ids, nio);
+        memcpy(pb + nio, mask, nio);
+        if (types) memcpy(pb + 2 * nio, types, nio);
+        MI_HIP(hipMemcpyAsync(d_ids, pb, nio, hipMemcpyHostToDevice, st));
+        MI_HIP(hipMemcpyAsync(d_mask, pb + nio, nio, hipMemcpyHostToDevice, st));
+        if (types) MI_HIP(hipMemcpyAsync(d_types, pb + 2 * nio, nio, hipMemcpyHostToDevice, st));
+    } else {
+        MI_HIP(hipMemcpyAsync(d_ids, ids, nio, hipMemcpyHostToDevice, st));
+        MI_HIP(hipMemcpyAsync(d_mask, mask, nio, hipMemcpyHostToDevice, st));
+        if (types) MI_HIP(hipMemcpyAsync(d_types, types, nio, hipMemcpyHostToDevice, st));
+    }
+    MI_TRY(encode_dev_locked(e, B, L, d_ids, d_types, d_mask, logits ? nullptr : e->d_out, logits ? e->d_out : nullptr, st));
+    if (pinned) {
+        MI_HIP(hipMemcpyAsync(e->pin_out[0].p, e->d_out, nout, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipStreamSynchronize(st));
+        memcpy(out, e->pin_out[0].p, nout);
+    } else {
+        MI_HIP(hipMemcpyAsync(out, e->d_out, nout, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipStreamSynchronize(st));
+    }
+    return MI_OK;
 }
 
 extern "C" int mi_encoder_encode(mi_encoder* e, int64_t B, int L, const int32_t* ids, const int32_t* mask, float* out_emb)
@@ -1681,43 +1904,128 @@ extern "C" int mi_encoder_encode(mi_encoder* e, int64_t B, int L, const int32_t*
     if (B == 0) return MI_OK;
     MI_REQUIRE(ids && mask && out_emb, "mi_encoder_encode: NULL buffer");
     MI_REQUIRE(L <= e->cfg.max_position_embeddings, "mi_encoder_encode: L=%d exceeds max_position_embeddings=%d", L, e->cfg.max_position_embeddings);
-    for (int64_t i = 0; i < B * L; ++i)
-        if (ids[i] < 0 || ids[i] >= e->cfg.vocab_size) { mi_set_error("mi_encoder_encode: token id %d at position %lld outside [0,%d)", ids[i], (long long)i, e->cfg.vocab_size); return MI_ERR_INVALID_ARG; }
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    if (prev != e->device) (void)hipSetDevice(e->device);
-    int rc = MI_OK;
-    {
-        std::lock_guard<std::mutex> lk(e->mu);
-        const size_t nio = (size_t)B * L * sizeof(int32_t), nout = (size_t)B * e->cfg.hidden_size * sizeof(float);
-        if (nio > e->io_cap) {
-            if (e->d_ids) (void)hipFree(e->d_ids);
-            if (e->d_mask) (void)hipFree(e->d_mask);
-            e->d_ids = e->d_mask = nullptr; e->io_cap = 0;
-            if (hipMalloc((void**)&e->d_ids, nio) != hipSuccess || hipMalloc((void**)&e->d_mask, nio) != hipSuccess) { mi_set_error("mi_encoder_encode: hipMalloc failed"); rc = MI_ERR_OOM; }
-            else e->io_cap = nio;
-        }
-        if (rc == MI_OK && nout > e->out_cap) {
-            if (e->d_out) (void)hipFree(e->d_out);
-            e->d_out = nullptr; e->out_cap = 0;
-            if (hipMalloc((void**)&e->d_out, nout) != hipSuccess) { mi_set_error("mi_encoder_encode: hipMalloc failed"); rc = MI_ERR_OOM; }
-            else e->out_cap = nout;
-        }
-        if (rc == MI_OK) {
-            hipStream_t st = e->stream;
-            hipError_t er = hipMemcpyAsync(e->d_ids, ids, nio, hipMemcpyHostToDevice, st);
-            if (er == hipSuccess) er = hipMemcpyAsync(e->d_mask, mask, nio, hipMemcpyHostToDevice, st);
-            if (er != hipSuccess) { mi_set_error("mi_encoder_encode: H2D copy failed: %s", hipGetErrorString(er)); rc = MI_ERR_HIP; }
-        }
+    return encode_host(e, "mi_encoder_encode", B, L, ids, nullptr, mask, out_emb, false);
+}
+
+extern "C" int mi_encoder_classify(mi_encoder* e, int64_t B, int L, const int32_t* ids, const int32_t* type_ids,
+                                   const int32_t* mask, float* out_logits)
+{
+    MI_REQUIRE(e && B >= 0 && L > 0, "mi_encoder_classify: bad argument");
+    if (B == 0) return MI_OK;
+    MI_REQUIRE(ids && mask && out_logits, "mi_encoder_classify: NULL buffer");
+    MI_REQUIRE(L <= e->cfg.max_position_embeddings, "mi_encoder_classify: L=%d exceeds max_position_embeddings=%d", L, e->cfg.max_position_embeddings);
+    if (type_ids)
+        for (int64_t i = 0; i < B * L; ++i)
+            if (type_ids[i] < 0 || type_ids[i] >= e->cfg.type_vocab_size) {
+                mi_set_error("mi_encoder_classify: token type %d at position %lld outside [0,%d)", type_ids[i], (long long)i, e->cfg.type_vocab_size);
+                return MI_ERR_INVALID_ARG;
+            }
+    return encode_host(e, "mi_encoder_classify", B, L, ids, type_ids, mask, out_logits, true);
+}
+
+// Ragged bulk embedding: n sequences as one flat token array + offsets (sequence i = flat_ids[offsets[i] ..
+// offsets[i + 1])), results in input order.  This is sentence-transformers' encode loop moved below the boundary:
+// sort by length (longest first), cut into passes, pad each pass to its longest sequence -- but a pass is cut by a
+// TOKEN budget (MI_ENC_PASS_TOKENS, 64K) instead of a fixed 32 rows, so bulk calls reach the fused per-tile kernels
+// whatever the length mix.  Passes are staged through two pinned blocks: the host packs pass i + 1 (and unpacks
+// pass i - 1) while the GPU runs pass i.
+extern "C" int mi_encoder_encode_ragged(mi_encoder* e, int64_t n, const int32_t* flat_ids, const int64_t* offsets,
+                                        int max_len, int max_batch, float* out_emb)
+{
+    MI_REQUIRE(e && n >= 0, "mi_encoder_encode_ragged: bad argument");
+    if (n == 0) return MI_OK;
+    MI_REQUIRE(flat_ids && offsets && out_emb, "mi_encoder_encode_ragged: NULL buffer");
+    MI_REQUIRE(max_len >= 0 && max_batch >= 0, "mi_encoder_encode_ragged: max_len / max_batch must be >= 0 (0 = no limit)");
+    const int Lcap = (max_len > 0 && max_len < e->cfg.max_position_embeddings) ? max_len : e->cfg.max_position_embeddings;
+    const int H = e->cfg.hidden_size;
+    std::vector<int32_t> lens((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t len = offsets[i + 1] - offsets[i];
+        MI_REQUIRE(offsets[i] >= 0 && len >= 0, "mi_encoder_encode_ragged: offsets must be non-decreasing (sequence %lld)", (long long)i);
+        lens[(size_t)i] = (int32_t)(len < Lcap ? len : Lcap);               // truncation, as the tokenizer's max_length would
+        MI_TRY(check_ids("mi_encoder_encode_ragged", e, flat_ids + offsets[i], lens[(size_t)i]));
     }
-    if (rc == MI_OK) rc = mi_encoder_encode_dev(e, B, L, e->d_ids, e->d_mask, e->d_out, e->stream);
-    if (rc == MI_OK) {
-        hipError_t er = hipMemcpyAsync(out_emb, e->d_out, (size_t)B * e->cfg.hidden_size * sizeof(float), hipMemcpyDeviceToHost, e->stream);
-        if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
-        if (er != hipSuccess) { mi_set_error("mi_encoder_encode: D2H copy failed: %s", hipGetErrorString(er)); rc = MI_ERR_HIP; }
+    std::vector<int64_t> order((size_t)n);
+    for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return lens[(size_t)a] > lens[(size_t)b]; });
+
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard guard(e->device);
+    hipStream_t st = e->stream;
+    const int64_t budget = encoder_pass_tokens();
+    const int64_t bcap = (max_batch > 0 && max_batch < 4096) ? max_batch : 4096;          // rows per pass (bounds the pinned blocks)
+    struct Pass { int64_t first, B; int L; };
+    // cut the passes first: every buffer is then sized once, for the largest of them
+    std::vector<Pass> passes;
+    size_t Tmax = 0, Bmax = 0;
+    for (int64_t next = 0; next < n;) {
+        int L = lens[(size_t)order[(size_t)next]];
+        if (L < 1) L = 1;                                // an empty sequence: one padding token, all-masked -> zero vector
+        int64_t B = budget / L;
+        if (B < 1) B = 1;
+        if (B > bcap) B = bcap;
+        if (B > n - next) B = n - next;
+        passes.push_back({next, B, L});
+        if ((size_t)B * L > Tmax) Tmax = (size_t)B * L;
+        if ((size_t)B > Bmax) Bmax = (size_t)B;
+        next += B;
     }
-    if (prev != e->device && prev >= 0) (void)hipSetDevice(prev);
-    return rc;
+    const size_t io_bytes = std::max(2 * Tmax * sizeof(int32_t), (size_t)1 << 20), out_bytes = std::max(Bmax * H * sizeof(float), (size_t)1 << 20);
+    MI_TRY(ensure_io(e, Tmax, Bmax * H * sizeof(float), st));
+    MI_TRY(ensure_ws(e, (int64_t)Tmax, st));
+    for (int s = 0; s < 2 && s < (int)passes.size(); ++s) { MI_TRY(e->pin_io[s].ensure(io_bytes)); MI_TRY(e->pin_out[s].ensure(out_bytes)); }
+    Pass inflight[2] = {{0, 0, 0}, {0, 0, 0}};
+    auto unpack = [&](int s) -> int {                    // results of the pass staged in set s -> caller's rows
+        if (inflight[s].B == 0) return MI_OK;
+        MI_HIP(hipEventSynchronize(e->ev_pin[s]));
+        const float* src = static_cast<const float*>(e->pin_out[s].p);
+        for (int64_t r = 0; r < inflight[s].B; ++r)
+            memcpy(out_emb + order[(size_t)(inflight[s].first + r)] * H, src + r * H, (size_t)H * sizeof(float));
+        inflight[s].B = 0;
+        return MI_OK;
+    };
+    for (size_t pi = 0; pi < passes.size(); ++pi) {
+        const int s = (int)(pi & 1);
+        const Pass ps = passes[pi];
+        const int L = ps.L;
+        const int64_t B = ps.B;
+        MI_TRY(unpack(s));                               // set s is free once its previous pass has been read back
+        const size_t T = (size_t)B * L;
+        int32_t* pid = static_cast<int32_t*>(e->pin_io[s].p);
+        int32_t* pmask = pid + T;
+        for (int64_t r = 0; r < B; ++r) {
+            const int64_t i = order[(size_t)(ps.first + r)];
+            const int len = lens[(size_t)i];
+            memcpy(pid + r * L, flat_ids + offsets[i], (size_t)len * sizeof(int32_t));
+            for (int c = 0; c < len; ++c) pmask[r * L + c] = 1;
+            if (len < L) {
+                memset(pid + r * L + len, 0, (size_t)(L - len) * sizeof(int32_t));
+                memset(pmask + r * L + len, 0, (size_t)(L - len) * sizeof(int32_t));
+            }
+        }
+        int32_t* d_ids = e->d_io;
+        int32_t* d_mask = e->d_io + 2 * Tmax;
+        MI_HIP(hipMemcpyAsync(d_ids, pid, T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        MI_HIP(hipMemcpyAsync(d_mask, pmask, T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        MI_TRY(encode_pass_locked(e, B, L, d_ids, nullptr, d_mask, e->d_out, nullptr, st, nullptr, 0));
+        MI_HIP(hipMemcpyAsync(e->pin_out[s].p, e->d_out, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, st));
+        MI_HIP(hipEventRecord(e->ev_pin[s], st));
+        inflight[s] = ps;
+    }
+    // oldest first
+    const int s_old = (inflight[0].B && inflight[1].B && inflight[1].first < inflight[0].first) ? 1 : 0;
+    MI_TRY(unpack(s_old));
+    MI_TRY(unpack(s_old ^ 1));
+    return MI_OK;
+}
+
+extern "C" int mi_encoder_stats(const mi_encoder* enc, int64_t out[4])
+{
+    MI_REQUIRE(enc && out, "mi_encoder_stats: NULL argument");
+    mi_encoder* e = const_cast<mi_encoder*>(enc);
+    std::lock_guard<std::mutex> lk(e->mu);
+    out[0] = e->st_seqs; out[1] = e->st_tokens; out[2] = e->st_bulk; out[3] = e->st_latency;
+    return MI_OK;
 }
 
 extern "C" int mi_encoder_last_time(const mi_encoder* enc, float* out_ms)
@@ -1725,6 +2033,7 @@ extern "C" int mi_encoder_last_time(const mi_encoder* enc, float* out_ms)
     MI_REQUIRE(enc && out_ms, "mi_encoder_last_time: NULL argument");
     mi_encoder* e = const_cast<mi_encoder*>(enc);
     std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard guard(e->device);
     *out_ms = 0.0f;
     if (!e->timed) return MI_OK;
     MI_HIP(hipEventSynchronize(e->ev1));

@@ -37,6 +37,16 @@ int mi_select_dense_pieces(int nrows, int nq, int k, int* seg_len);
 int mi_launch_merge(hipStream_t st, int metric, int64_t nq, int m, const float* in_s,
                     const int64_t* in_i, int64_t in_stride, int k, float* out_s, int64_t* out_i,
                     int64_t out_stride);
+// The same per chunk of `chunk` (<= 4096) consecutive entries: grid (nq, ceil(m / chunk)); chunk c's k best land
+// at out[q * out_stride + c * k ..] (padded with id -1 where the chunk holds fewer).
+int mi_launch_merge_chunks(hipStream_t st, int metric, int64_t nq, int m, int chunk, const float* in_s,
+                           const int64_t* in_i, int64_t in_stride, int k, float* out_s, int64_t* out_i,
+                           int64_t out_stride);
+// General form: entry i of query q is element i % k_in of list i / k_in, stored at l * lstride + q * qstride + j
+// (see merge_kernel), chunked as above.
+int mi_launch_merge_ex(hipStream_t st, int metric, int64_t nq, int m, int chunk, const float* in_s, const int64_t* in_i,
+                       int k_in, int64_t lstride_s, int64_t lstride_i, int64_t qstride,
+                       int k, float* out_s, int64_t* out_i, int64_t out_stride);
 int mi_launch_fill_pad(hipStream_t st, int metric, int64_t nq, int k, float* s, int64_t* i,
                        int64_t stride);
 // out[dst_q[j]] rows <- in[j] rows (scatter of re-run queries); dst_q == nullptr: identity.

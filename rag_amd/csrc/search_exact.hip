@@ -419,21 +419,29 @@ int mi_launch_select_dense(hipStream_t st, const float* S, int64_t s_stride, int
 #define MERGE_MAX 4096
 #define MERGE_THREADS 256
 
-__global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(int metric, int m, int P,
-        const float* __restrict__ in_s, const int64_t* __restrict__ in_i, int64_t in_stride, int k,
-        float* __restrict__ out_s, int64_t* __restrict__ out_i, int64_t out_stride)
+// blockIdx.y = chunk: entries [y * chunk, min(m_all, (y + 1) * chunk)) of the query, k best to out[.. + y * k].
+// Entry i of query q is element j = i % k_in of list l = i / k_in, stored at l * lstride + q * qstride + j:
+//   one row per query, lists side by side  ([nq][nlists * k_in]):  lstride = k_in, qstride = row stride;
+//   one block per list, as an all-gather leaves them ([nlists][nq][k_in]):  lstride = block stride, qstride = k_in.
+__global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(int metric, int m_all, int chunk, int P,
+        const float* __restrict__ in_s, const int64_t* __restrict__ in_i, int k_in, int64_t lstride_s, int64_t lstride_i,
+        int64_t qstride, int k, float* __restrict__ out_s, int64_t* __restrict__ out_i, int64_t out_stride)
 {
     __shared__ uint32_t rk[MERGE_MAX];
     __shared__ int64_t id[MERGE_MAX];
     const int t = threadIdx.x;
     const int64_t q = blockIdx.x;
+    const int e0 = (int)blockIdx.y * chunk;
+    const int m = (m_all - e0 < chunk) ? m_all - e0 : chunk;
+    out_s += (int64_t)blockIdx.y * k; out_i += (int64_t)blockIdx.y * k;
     for (int i = t; i < P; i += MERGE_THREADS) {
         uint32_t r = 0;
         int64_t v = INT64_MAX;
         if (i < m) {
-            const int64_t x = in_i[q * in_stride + i];
+            const int l = (e0 + i) / k_in, j = (e0 + i) - l * k_in;
+            const int64_t x = in_i[l * lstride_i + q * qstride + j];
             if (x >= 0) {
-                float s = in_s[q * in_stride + i];
+                float s = in_s[l * lstride_s + q * qstride + j];
                 if (metric == MI_METRIC_L2) { if (s != s) s = __builtin_inff(); s += 0.0f; r = ~mi_ord_f32(s); }
                 else { if (s != s) s = -__builtin_inff(); s += 0.0f; r = mi_ord_f32(s); }
                 v = x;
@@ -464,15 +472,34 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(int metric, int m,
     }
 }
 
+int mi_launch_merge_ex(hipStream_t st, int metric, int64_t nq, int m, int chunk, const float* in_s, const int64_t* in_i,
+                       int k_in, int64_t lstride_s, int64_t lstride_i, int64_t qstride,
+                       int k, float* out_s, int64_t* out_i, int64_t out_stride)
+{
+    if (nq <= 0 || m <= 0) return MI_OK;
+    if (chunk < 1 || chunk > MERGE_MAX || k_in < 1) { mi_set_error("merge: chunk %d outside [1, %d]", chunk, MERGE_MAX); return MI_ERR_INTERNAL; }
+    const int nch = (m + chunk - 1) / chunk;
+    if (nq > 0x7FFFFFFF || nch > 65535) { mi_set_error("merge: grid too large"); return MI_ERR_INTERNAL; }
+    const int P = mi_next_pow2(chunk < m ? chunk : m);
+    merge_kernel<<<dim3((unsigned)nq, (unsigned)nch), MERGE_THREADS, 0, st>>>(metric, m, chunk, P, in_s, in_i, k_in, lstride_s, lstride_i,
+                                                                            qstride, k, out_s, out_i, out_stride);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+
 int mi_launch_merge(hipStream_t st, int metric, int64_t nq, int m, const float* in_s, const int64_t* in_i,
                     int64_t in_stride, int k, float* out_s, int64_t* out_i, int64_t out_stride)
 {
     if (nq <= 0) return MI_OK;
     if (m > MERGE_MAX) { mi_set_error("merge: %d entries per query exceeds %d", m, MERGE_MAX); return MI_ERR_INTERNAL; }
-    const int P = mi_next_pow2(m > 1 ? m : 1);
-    merge_kernel<<<(unsigned)nq, MERGE_THREADS, 0, st>>>(metric, m, P, in_s, in_i, in_stride, k, out_s, out_i, out_stride);
-    MI_HIP(hipGetLastError());
-    return MI_OK;
+    if (m <= 0) return mi_launch_fill_pad(st, metric, nq, k, out_s, out_i, out_stride);
+    return mi_launch_merge_ex(st, metric, nq, m, m, in_s, in_i, m, 0, 0, in_stride, k, out_s, out_i, out_stride);
+}
+
+int mi_launch_merge_chunks(hipStream_t st, int metric, int64_t nq, int m, int chunk, const float* in_s, const int64_t* in_i,
+                           int64_t in_stride, int k, float* out_s, int64_t* out_i, int64_t out_stride)
+{
+    return mi_launch_merge_ex(st, metric, nq, m, chunk, in_s, in_i, m, 0, 0, in_stride, k, out_s, out_i, out_stride);
 }
 
 // ---------------------------------------------------------------- small list utilities

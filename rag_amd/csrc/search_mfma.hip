@@ -740,11 +740,16 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
 //   accumulation: both are fp32 sums of the same terms in different orders, |diff| <= eps_acc * sum|terms|,
 //                 sum|terms| <= |q||x| (+ xx/2 + qq/2 for L2, which also covers the rounding of the distance formula)
 //   rounding    : |q.x - q~.x~| <= eps_round * |q||x|  (bf16 shadow of an F32 index; 0 for a BF16 index)
+//   underflow   : d * 2^-125 absolute (flushed denormal products / partial sums)
 __device__ __forceinline__ float mf_err_bound(int metric, float qqv, float mx, float eps_acc, float eps_round)
 {
-    const float qx = sqrtf(qqv * mx);
+    const float qx = sqrtf(qqv) * sqrtf(mx);              // not sqrtf(qqv * mx): the product leaves the fp32 range first
     float E = (eps_acc + eps_round) * qx;
     if (metric == MI_METRIC_L2) E += eps_acc * 0.5f * (qqv + mx);
+    // absolute floor, d * 2^-125 (eps_acc = 4 d 2^-24): products and partial sums below the normal range may be
+    // flushed by the MFMA while the canonical chain keeps them as denormals -- a relative bound alone goes to zero
+    // with the norms and would certify a list the scan never ordered
+    E += eps_acc * 9.8607613e-32f;
     return E;
 }
 

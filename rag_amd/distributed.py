@@ -1,15 +1,21 @@
-"""Row-sharded flat search over the GPUs of one node.
+"""Row-sharded flat search and data-parallel embedding over the GPUs of one node.
 
-One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).  Rank r owns the
-contiguous row block [r*ceil(N/G), min(N, (r+1)*ceil(N/G))) and reports GLOBAL ids
-(mi_index_set_id_base).  A search is: local exact top-k on every rank -> ONE all-gather of the
-per-rank (score, id) lists (Q*k*12 bytes per rank: latency-bound, not link-bound) -> the same
-deterministic merge on every rank, so every rank returns the identical answer, equal to the
-single-index answer.  There is no other collective on the path.
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).
 
-The local engine and the merge are injectable so the sharding / gather logic can be covered
-by world_size-2 gloo tests on CPU (tests/test_distributed_cpu.py injects the oracle there);
-the defaults are the HIP engine and the HIP merge, and nothing else ships.
+Search.  Rank r owns the contiguous row block [r*ceil(N/G), min(N, (r+1)*ceil(N/G))) and reports GLOBAL ids
+(mi_index_set_id_base).  A search is: local exact top-k on every rank, written straight into the rank's
+packed block ([nq][k] fp32 scores | [nq][k] int64 ids, mi_topk_packed_layout) -> ONE all-gather of that block
+(Q*k*12 bytes per rank: latency-bound, not link-bound) -> the same deterministic merge on every rank, reading
+the rank-major blocks in place (mi_topk_merge_packed_dev).  Every rank returns the identical answer, equal to
+the single-index answer.  There is no other collective, and no transpose or copy between the two steps.
+
+Embedding (advanced_rag.py:295 at BASELINE config 3's scale) is pure data parallel: rank r encodes the
+contiguous chunk range shard_range(n, G, r); no collective on the path, an optional all-gather of the
+[n][hidden] result when every rank needs all of it.
+
+The local engine, the merge and the encoder are injectable so the sharding / gather logic can be covered by
+world_size-2 gloo tests on CPU (tests/test_distributed_cpu.py injects the oracle there); the defaults are the
+HIP engine and the HIP merge, and nothing else ships.
 """
 from __future__ import annotations
 
@@ -23,6 +29,12 @@ def shard_range(n_total: int, world: int, rank: int) -> Tuple[int, int]:
     lo = min(n_total, rank * per)
     hi = min(n_total, lo + per)
     return lo, hi
+
+
+def packed_layout(nq: int, k: int) -> Tuple[int, int]:
+    """(ids_offset, block_bytes) of one rank's packed result block; mirrors mi_topk_packed_layout."""
+    off = (nq * k * 4 + 255) & ~255
+    return off, (off + nq * k * 8 + 255) & ~255
 
 
 class ShardedFlatIndex:
@@ -44,7 +56,7 @@ class ShardedFlatIndex:
             local_index = FlatIndex(d, metric=metric, dtype=dtype, device=dev)
         self.local = local_index
         self._merge = merge_fn
-        self._on_gpu = hasattr(self.local, "search_torch")
+        self._on_gpu = hasattr(self.local, "search_packed")
 
     # ---- build
     def add_global(self, X: np.ndarray) -> None:
@@ -66,30 +78,76 @@ class ShardedFlatIndex:
         self.n_total = n_total
 
     # ---- search
+    def search_torch(self, q, k: int):
+        """GPU path: q is a contiguous fp32 CUDA tensor [nq][d], identical on every rank.  Returns CUDA tensors
+        (scores [nq][k], ids [nq][k]), identical on every rank."""
+        import torch
+        nq = q.shape[0]
+        _, block = packed_layout(nq, k)
+        gathered = torch.empty((self.world, block), dtype=torch.uint8, device=q.device)
+        if self.world > 1:
+            mine = torch.empty((block,), dtype=torch.uint8, device=q.device)
+            self.local.search_packed(q, k, mine)
+            self.dist.all_gather_into_tensor(gathered.view(-1), mine, group=self.group)     # THE collective
+        else:
+            self.local.search_packed(q, k, gathered[0])
+        from .index import topk_merge_packed_torch
+        return topk_merge_packed_torch(gathered, nq, self.world, k, k, self.metric)
+
     def search(self, Q, k: int):
         """Q: [nq][d] fp32 (NumPy, or a CUDA tensor on the GPU path), identical on every rank.
         Returns (scores [nq][k], ids [nq][k]) as NumPy arrays, identical on every rank."""
         import torch
-        dist = self.dist
         if self._on_gpu:
             q = Q if torch.is_tensor(Q) else torch.from_numpy(np.ascontiguousarray(Q, dtype=np.float32)).cuda()
-            D, I = self.local.search_torch(q.contiguous(), k)
-        else:
-            Dn, In = self.local.search(np.asarray(Q, dtype=np.float32), k)
-            D, I = torch.from_numpy(Dn), torch.from_numpy(In)
-        nq = D.shape[0]
+            D, I = self.search_torch(q.contiguous(), k)
+            return D.cpu().numpy(), I.cpu().numpy()
+        # host engines (the CPU tests): same block layout, same single collective
+        Dn, In = self.local.search(np.asarray(Q, dtype=np.float32), k)
+        nq = Dn.shape[0]
+        off, block = packed_layout(nq, k)
+        mine = np.zeros(block, dtype=np.uint8)
+        mine[:nq * k * 4] = np.ascontiguousarray(Dn, dtype=np.float32).view(np.uint8).reshape(-1)
+        mine[off:off + nq * k * 8] = np.ascontiguousarray(In, dtype=np.int64).view(np.uint8).reshape(-1)
+        gathered = torch.empty((self.world, block), dtype=torch.uint8)
         if self.world > 1:
-            Dg = torch.empty((self.world * nq, k), dtype=D.dtype, device=D.device)   # rank-major concat
-            Ig = torch.empty((self.world * nq, k), dtype=I.dtype, device=I.device)
-            dist.all_gather_into_tensor(Dg, D.contiguous(), group=self.group)
-            dist.all_gather_into_tensor(Ig, I.contiguous(), group=self.group)
-            Dm = Dg.view(self.world, nq, k).permute(1, 0, 2).reshape(nq, self.world * k).contiguous()
-            Im = Ig.view(self.world, nq, k).permute(1, 0, 2).reshape(nq, self.world * k).contiguous()
-            D, I = self._merge_lists(Dm, Im, k)
-        return D.cpu().numpy(), I.cpu().numpy()
+            self.dist.all_gather_into_tensor(gathered.view(-1), torch.from_numpy(mine), group=self.group)
+        else:
+            gathered[0] = torch.from_numpy(mine)
+        g = gathered.numpy()
+        Dm = np.concatenate([g[r, :nq * k * 4].view(np.float32).reshape(nq, k) for r in range(self.world)], axis=1)
+        Im = np.concatenate([g[r, off:off + nq * k * 8].view(np.int64).reshape(nq, k) for r in range(self.world)], axis=1)
+        if self._merge is None:
+            raise RuntimeError("a host engine needs a merge_fn (the HIP merge runs on device tensors only)")
+        D, I = self._merge(torch.from_numpy(Dm), torch.from_numpy(Im), k, self.metric)
+        return D.numpy(), I.numpy()
 
-    def _merge_lists(self, Dm, Im, k):
-        if self._merge is not None:
-            return self._merge(Dm, Im, k, self.metric)
-        from .index import topk_merge_torch
-        return topk_merge_torch(Dm, Im, k, self.metric)
+
+def embed_sharded(encoder, flat_ids: np.ndarray, offsets: np.ndarray, group=None, gather: bool = True,
+                  max_len: int = 0) -> np.ndarray:
+    """Data-parallel bulk embedding (BASELINE config 3): every rank is handed the same n ragged sequences (CSR),
+    encodes the contiguous range shard_range(n, world, rank) with `encoder.encode_ragged` -- no collective -- and,
+    when `gather`, the [n][hidden] result is all-gathered so every rank returns all rows; otherwise a rank
+    returns only its own rows.  `encoder`: rag_amd.embeddings.Encoder, or anything with its encode_ragged."""
+    import torch
+    import torch.distributed as dist
+    on = dist.is_initialized()
+    rank = dist.get_rank(group) if on else 0
+    world = dist.get_world_size(group) if on else 1
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = offsets.size - 1
+    lo, hi = shard_range(n, world, rank)
+    sub_off = offsets[lo:hi + 1] - offsets[lo]
+    sub_ids = np.ascontiguousarray(flat_ids[offsets[lo]:offsets[hi]], dtype=np.int32)
+    E = encoder.encode_ragged(sub_ids, sub_off, max_len=max_len) if hi > lo else np.zeros((0, encoder.hidden_size), np.float32)
+    if not gather or world == 1:
+        return E
+    per = (n + world - 1) // world
+    H = E.shape[1]
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    mine = torch.zeros((per, H), dtype=torch.float32, device=dev)
+    mine[:hi - lo] = torch.from_numpy(E).to(dev)
+    out = torch.empty((world * per, H), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out[:n].cpu().numpy()

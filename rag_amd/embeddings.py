@@ -67,11 +67,61 @@ class Encoder:
         import torch
         B, L = ids.shape
         out = torch.empty((B, self.hidden_size), dtype=torch.float32, device=ids.device)
-        stream = torch.cuda.current_stream(ids.device).cuda_stream
+        stream = _capi.stream_arg(ids.device)
         _capi.check(self._lib.mi_encoder_encode_dev(self._h, B, L, ctypes.c_void_p(ids.data_ptr()),
                                                     ctypes.c_void_p(mask.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                                    ctypes.c_void_p(stream)))
+                                                    stream))
         return out
+
+    def encode_ragged(self, flat_ids: np.ndarray, offsets: np.ndarray, max_len: int = 0, max_batch: int = 0) -> np.ndarray:
+        """n ragged sequences (CSR: flat token ids + offsets [n + 1]) -> [n][hidden], input order.  Length-sorted,
+        token-budget batching and pinned double-buffered staging happen inside the library (mi_encoder_encode_ragged)."""
+        flat_ids = np.ascontiguousarray(flat_ids, dtype=np.int32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if offsets.ndim != 1 or offsets.size < 1 or offsets[0] != 0 or offsets[-1] != flat_ids.size:
+            raise ValueError("offsets must be [n + 1], start at 0 and end at len(flat_ids)")
+        n = offsets.size - 1
+        out = np.empty((n, self.hidden_size), dtype=np.float32)
+        _capi.check(self._lib.mi_encoder_encode_ragged(self._h, n, flat_ids.ctypes.data_as(ctypes.c_void_p),
+                                                       offsets.ctypes.data_as(ctypes.c_void_p), int(max_len), int(max_batch),
+                                                       out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def set_head(self, pooler_w, pooler_b, cls_w, cls_b) -> None:
+        """Loads a BertForSequenceClassification head (pooler dense + classifier), fp32."""
+        H = self.hidden_size
+        pw = np.ascontiguousarray(pooler_w, dtype=np.float32)
+        pb = np.ascontiguousarray(pooler_b, dtype=np.float32)
+        cw = np.ascontiguousarray(cls_w, dtype=np.float32)
+        cb = np.ascontiguousarray(cls_b, dtype=np.float32)
+        if pw.shape != (H, H) or pb.shape != (H,) or cw.ndim != 2 or cw.shape[1] != H or cb.shape != (cw.shape[0],):
+            raise ValueError("head shapes: pooler_w [H][H], pooler_b [H], cls_w [num_labels][H], cls_b [num_labels]")
+        self.num_labels = int(cw.shape[0])
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)          # noqa: E731
+        _capi.check(self._lib.mi_encoder_set_head(self._h, p(pw), p(pb), p(cw), p(cb), self.num_labels))
+
+    def classify(self, ids: np.ndarray, type_ids: Optional[np.ndarray], mask: np.ndarray) -> np.ndarray:
+        """Cross-encoder logits [B][num_labels] for padded (query, passage) pair batches."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        mask = np.ascontiguousarray(mask, dtype=np.int32)
+        if ids.ndim != 2 or ids.shape != mask.shape:
+            raise ValueError("ids and mask must be [B][L] arrays of the same shape")
+        tp = None
+        if type_ids is not None:
+            type_ids = np.ascontiguousarray(type_ids, dtype=np.int32)
+            if type_ids.shape != ids.shape:
+                raise ValueError("type_ids must have the shape of ids")
+            tp = type_ids.ctypes.data_as(ctypes.c_void_p)
+        B, L = ids.shape
+        out = np.empty((B, getattr(self, "num_labels", 1)), dtype=np.float32)
+        _capi.check(self._lib.mi_encoder_classify(self._h, B, L, ids.ctypes.data_as(ctypes.c_void_p), tp,
+                                                  mask.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def stats(self) -> dict:
+        out = (ctypes.c_int64 * 4)()
+        _capi.check(self._lib.mi_encoder_stats(self._h, out))
+        return {"sequences": out[0], "tokens": out[1], "bulk_passes": out[2], "latency_passes": out[3]}
 
     def last_time_ms(self) -> float:
         ms = ctypes.c_float()
@@ -109,6 +159,7 @@ class MI355Embeddings:
         if isinstance(dev, str):
             dev = int(dev.split(":")[1]) if ":" in dev else 0
         self.device = int(dev)
+        self._batch_size_set = "batch_size" in self.encode_kwargs
         self.batch_size = int(self.encode_kwargs.get("batch_size", 32))
         normalize = bool(self.encode_kwargs.get("normalize_embeddings", True))
         cfg, blob = load_local_dir(model_name, normalize=normalize)
@@ -116,30 +167,32 @@ class MI355Embeddings:
         self.tokenizer = _load_tokenizer(model_name, self.max_seq_length)
         self.encoder = Encoder(cfg, blob, device=self.device)
 
-    # ---- tokenisation + length-sorted batching (sentence-transformers' encode loop)
+    # ---- tokenisation; the length-sorted batching of sentence-transformers' encode loop lives in the library
     def _tokenize(self, texts: List[str]):
         return [e.ids for e in self.tokenizer.encode_batch(texts)]
+
+    @staticmethod
+    def _to_csr(toks) -> tuple:
+        lens = np.fromiter((len(t) for t in toks), dtype=np.int64, count=len(toks))
+        offsets = np.zeros(len(toks) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        flat = np.fromiter((i for t in toks for i in t), dtype=np.int32, count=int(offsets[-1]))
+        return flat, offsets
+
+    def embed_tokenized(self, flat_ids: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+        """Token ids in (CSR), embeddings out, input order: the step of embed_documents below the tokenizer.
+        `encode_kwargs["batch_size"]` caps the rows per pass only when the caller set it; by default a pass is cut
+        by the library's token budget, so a bulk call (FAISS.from_documents, advanced_rag.py:295) runs the fused
+        bulk kernels."""
+        return self.encoder.encode_ragged(flat_ids, offsets, max_len=self.max_seq_length,
+                                          max_batch=self.batch_size if self._batch_size_set else 0)
 
     def embed_documents_array(self, texts: List[str]) -> np.ndarray:
         texts = [t.replace("\n", " ") for t in texts]
         if not texts:
             return np.zeros((0, self.encoder.hidden_size), dtype=np.float32)
-        toks = self._tokenize(texts)
-        order = np.argsort([-len(t) for t in toks], kind="stable")
-        out = np.empty((len(texts), self.encoder.hidden_size), dtype=np.float32)
-        bs = max(self.batch_size, 1)
-        for s in range(0, len(order), bs):
-            sel = order[s:s + bs]
-            L = max(len(toks[i]) for i in sel)
-            L = max(L, 1)
-            ids = np.zeros((len(sel), L), dtype=np.int32)
-            mask = np.zeros((len(sel), L), dtype=np.int32)
-            for r, i in enumerate(sel):
-                t = toks[i]
-                ids[r, :len(t)] = t
-                mask[r, :len(t)] = 1
-            out[sel] = self.encoder.encode_ids(ids, mask)
-        return out
+        flat, offsets = self._to_csr(self._tokenize(texts))
+        return self.embed_tokenized(flat, offsets)
 
     def embed_documents(self, texts: List[str]) -> List[List[float]]:
         return self.embed_documents_array(list(texts)).tolist()

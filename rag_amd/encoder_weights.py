@@ -101,7 +101,28 @@ def random_blob(cfg: BertConfig, seed: int = 0, init_range: float = 0.02) -> np.
     return np.concatenate(parts)
 
 
-def load_local_dir(path: str, normalize: bool = True):
+def head_from_state_dict(sd: Mapping[str, "np.ndarray"], cfg: BertConfig):
+    """(pooler_w, pooler_b, cls_w, cls_b) of a BertForSequenceClassification state_dict (cross-encoder)."""
+    def arr(t):
+        return t.detach().cpu().float().numpy() if hasattr(t, "detach") else np.asarray(t, dtype=np.float32)
+    g = {_strip(k): v for k, v in sd.items()}
+    H = cfg.hidden_size
+    pw, pb = arr(g["pooler.dense.weight"]), arr(g["pooler.dense.bias"])
+    cw, cb = arr(g["classifier.weight"]), arr(g["classifier.bias"])
+    if pw.shape != (H, H) or pb.shape != (H,) or cw.ndim != 2 or cw.shape[1] != H or cb.shape != (cw.shape[0],):
+        raise ValueError("classification head has unexpected shapes")
+    return pw, pb, cw, cb
+
+
+def random_head(cfg: BertConfig, num_labels: int = 1, seed: int = 0, init_range: float = 0.02):
+    rng = np.random.default_rng(seed)
+    H = cfg.hidden_size
+    return ((rng.standard_normal((H, H)) * init_range).astype(np.float32), (rng.standard_normal(H) * init_range).astype(np.float32),
+            (rng.standard_normal((num_labels, H)) * init_range).astype(np.float32),
+            (rng.standard_normal(num_labels) * init_range).astype(np.float32))
+
+
+def load_local_dir(path: str, normalize: bool = True, with_head: bool = False):
     """(BertConfig, blob) from a LOCAL directory holding config.json + model.safetensors
     (never a hub name: there is no network on the target machines)."""
     if not os.path.isdir(path):
@@ -114,4 +135,7 @@ def load_local_dir(path: str, normalize: bool = True):
     if not os.path.exists(st):
         sub = os.path.join(path, "0_Transformer", "model.safetensors")
         st = sub if os.path.exists(sub) else st
-    return cfg, pack_state_dict(load_file(st), cfg)
+    sd = load_file(st)
+    if with_head:
+        return cfg, pack_state_dict(sd, cfg), head_from_state_dict(sd, cfg)
+    return cfg, pack_state_dict(sd, cfg)

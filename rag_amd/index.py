@@ -68,9 +68,9 @@ class FlatIndex:
         if not x.is_cuda or x.dim() != 2 or x.shape[1] != self.d or not x.is_contiguous():
             raise ValueError("add_torch: need a contiguous [n][d] tensor on the GPU")
         src = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}[x.dtype]
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stream = _capi.stream_arg(x.device)
         _capi.check(self._lib.mi_index_add_dev(self._h, x.shape[0], ctypes.c_void_p(x.data_ptr()), src,
-                                               ctypes.c_void_p(stream)))
+                                               stream))
         torch.cuda.current_stream(x.device).synchronize()
 
     def add_synthetic(self, n: int, seed: int = 0, normalize: bool = True) -> None:
@@ -95,11 +95,28 @@ class FlatIndex:
         nq = q.shape[0]
         D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
-        stream = torch.cuda.current_stream(q.device).cuda_stream
+        stream = _capi.stream_arg(q.device)
         _capi.check(self._lib.mi_index_search_dev(self._h, nq, ctypes.c_void_p(q.data_ptr()), int(k),
                                                   ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
-                                                  ctypes.c_void_p(stream)))
+                                                  stream))
         return D, I
+
+    def search_packed(self, q, k: int, block) -> None:
+        """Device-resident search whose result lands in a packed block (uint8 CUDA tensor of
+        mi_topk_packed_layout(nq, k) bytes: [nq][k] fp32 scores | [nq][k] int64 ids) -- the message of the
+        sharded search's single all-gather (rag_amd.distributed)."""
+        import torch
+        if not q.is_cuda or q.dtype != torch.float32 or q.dim() != 2 or q.shape[1] != self.d or not q.is_contiguous():
+            raise ValueError("search_packed: need a contiguous fp32 [nq][d] tensor on the GPU")
+        nq = q.shape[0]
+        off, nbytes = ctypes.c_size_t(), ctypes.c_size_t()
+        _capi.check(self._lib.mi_topk_packed_layout(nq, int(k), ctypes.byref(off), ctypes.byref(nbytes)))
+        if block.dtype != torch.uint8 or not block.is_contiguous() or block.numel() < nbytes.value or block.data_ptr() % 8:
+            raise ValueError(f"search_packed: block must be a contiguous, 8-byte aligned uint8 tensor of >= {nbytes.value} bytes")
+        stream = _capi.stream_arg(q.device)
+        _capi.check(self._lib.mi_index_search_dev(self._h, nq, ctypes.c_void_p(q.data_ptr()), int(k),
+                                                  ctypes.c_void_p(block.data_ptr()), ctypes.c_void_p(block.data_ptr() + off.value),
+                                                  stream))
 
     def reconstruct_n(self, row0: int, n: int) -> np.ndarray:
         out = np.empty((n, self.d), dtype=np.float32)
@@ -138,9 +155,27 @@ def topk_merge_torch(scores, ids, k: int, metric: str = "ip", device: Optional[i
     ids = ids.contiguous().long()
     D = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
     I = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
-    stream = torch.cuda.current_stream(scores.device).cuda_stream
+    stream = _capi.stream_arg(scores.device)
     met = {"l2": METRIC_L2, "ip": METRIC_IP}[metric.lower()]
     _capi.check(lib.mi_topk_merge_dev(ctx, met, nq, 1, m, ctypes.c_void_p(scores.data_ptr()),
                                       ctypes.c_void_p(ids.data_ptr()), int(k), ctypes.c_void_p(D.data_ptr()),
-                                      ctypes.c_void_p(I.data_ptr()), ctypes.c_void_p(stream)))
+                                      ctypes.c_void_p(I.data_ptr()), stream))
+    return D, I
+
+
+def topk_merge_packed_torch(packed, nq: int, nlists: int, k_in: int, k: int, metric: str = "ip", device: Optional[int] = None):
+    """Merge `nlists` packed blocks (rank-major, as all_gather_into_tensor leaves them; see FlatIndex.search_packed)
+    into ([nq][k] scores, [nq][k] ids), reading the blocks in place."""
+    import torch
+    lib = _capi.load()
+    dev = packed.device.index if device is None else device
+    ctx = _capi.get_ctx(dev or 0)
+    if packed.dtype != torch.uint8 or not packed.is_contiguous():
+        raise ValueError("topk_merge_packed_torch: need a contiguous uint8 tensor")
+    D = torch.empty((nq, k), dtype=torch.float32, device=packed.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=packed.device)
+    stream = _capi.stream_arg(packed.device)
+    met = {"l2": METRIC_L2, "ip": METRIC_IP}[metric.lower()]
+    _capi.check(lib.mi_topk_merge_packed_dev(ctx, met, nq, int(nlists), int(k_in), ctypes.c_void_p(packed.data_ptr()), int(k),
+                                             ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()), stream))
     return D, I

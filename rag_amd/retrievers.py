@@ -176,3 +176,52 @@ def rerank_pairs(query: str, documents: Sequence[Document], tokenizer: Any, max_
         types[i, :m] = e.type_ids[:m]
         mask[i, :m] = 1
     return ids, types, mask
+
+
+class CrossEncoderReranker:
+    """Scores (query, passage) pairs with a BERT cross-encoder on the MI355X and re-orders the candidates: the
+    consumer of BASELINE config 5's top-100 lists (README.md:27 and requirements.txt:24 name a reranker; the
+    reference code has none, so the surface follows sentence-transformers' CrossEncoder: `predict(pairs)` and
+    `rank`).  `model_name` is a LOCAL directory (config.json, model.safetensors with a
+    BertForSequenceClassification head, tokenizer.json or vocab.txt); or pass `encoder` + `tokenizer` built elsewhere.
+    One label: the score is the logit (`activation="sigmoid"` squashes it as CrossEncoder.predict does by default)."""
+
+    def __init__(self, model_name: Optional[str] = None, device: int = 0, max_length: int = 512,
+                 encoder: Any = None, tokenizer: Any = None, activation: Optional[str] = None):
+        from .embeddings import Encoder, _load_tokenizer
+        if encoder is None:
+            from .encoder_weights import load_local_dir
+            cfg, blob, head = load_local_dir(model_name, normalize=False, with_head=True)
+            encoder = Encoder(cfg, blob, device=device)
+            encoder.set_head(*head)
+            max_length = min(max_length, int(cfg.max_position_embeddings))
+            tokenizer = _load_tokenizer(model_name, max_length)
+        self.encoder, self.tokenizer, self.max_length, self.activation = encoder, tokenizer, int(max_length), activation
+
+    def predict(self, pairs: Sequence[Sequence[str]]):
+        import numpy as np
+        if not pairs:
+            return np.zeros((0,), dtype=np.float32)
+        docs = [Document(page_content=p[1]) for p in pairs]
+        queries = {p[0] for p in pairs}
+        if len(queries) == 1:
+            ids, types, mask = rerank_pairs(pairs[0][0], docs, self.tokenizer, self.max_length)
+        else:
+            parts = [rerank_pairs(p[0], [d], self.tokenizer, self.max_length) for p, d in zip(pairs, docs)]
+            L = max(a[0].shape[1] for a in parts)
+            ids, types, mask = (np.concatenate([np.pad(a[j], ((0, 0), (0, L - a[j].shape[1]))) for a in parts]) for j in range(3))
+        logits = self.encoder.classify(ids, types, mask)
+        s = logits[:, 0] if logits.shape[1] == 1 else logits
+        if self.activation == "sigmoid":
+            s = 1.0 / (1.0 + np.exp(-s))
+        return s
+
+    def rank(self, query: str, documents: Sequence[Document], top_n: Optional[int] = None) -> List[Document]:
+        """Candidates best first by cross-encoder score; ties keep the retriever's order."""
+        import numpy as np
+        docs = list(documents)
+        if not docs:
+            return []
+        s = self.predict([(query, d.page_content) for d in docs])
+        order = np.argsort(-s, kind="stable")
+        return [docs[i] for i in (order if top_n is None else order[:top_n])]

@@ -63,3 +63,25 @@ class HashEmbeddings:
 
     def embed_query(self, text):
         return self._one(text).tolist()
+
+
+class OracleEncoder:
+    """Oracle-backed stand-in for rag_amd.embeddings.Encoder.encode_ragged (one sequence per oracle call, padded
+    to its own length), so the data-parallel embedding split can be covered without a GPU.  Tests only."""
+
+    def __init__(self, cfg, blob):
+        self.cfg, self.blob = cfg, blob
+        self.hidden_size = int(cfg.hidden_size)
+        self.calls = 0
+
+    def encode_ragged(self, flat_ids, offsets, max_len=0, max_batch=0):
+        n = len(offsets) - 1
+        out = np.zeros((n, self.hidden_size), dtype=np.float32)
+        for i in range(n):
+            ids = np.asarray(flat_ids[offsets[i]:offsets[i + 1]], dtype=np.int32)
+            if max_len:
+                ids = ids[:max_len]
+            if ids.size:
+                out[i] = oracle.encode(self.cfg, self.blob, ids[None, :], np.ones((1, ids.size), dtype=np.int32))[0]
+        self.calls += 1
+        return out

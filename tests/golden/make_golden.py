@@ -9,6 +9,9 @@ restatements of the two algorithms, not from oracle/ and not from rag_amd/:
   search_*.npz   exact top-k by a pure-Python fmaf chain built on exact rational arithmetic
                  (fractions.Fraction + explicit round-to-nearest-even to binary32), ordered by
                  (score, id).  Includes planted duplicate rows and exact ties.
+  cross_encoder_small.npz  transformers.BertForSequenceClassification (the class a sentence-transformers
+                 CrossEncoder wraps) from a LOCAL BertConfig with seeded weights, CPU fp32, eager attention,
+                 one label: (query, passage) pair batches with token type ids -> logits.
   encoder_small.npz  transformers.BertModel (the library the reference's HuggingFaceEmbeddings
                  runs, requirements.txt:25) built from a LOCAL BertConfig with seeded weights,
                  CPU fp32, eager attention, + sentence-transformers' mean-pool / normalise
@@ -176,6 +179,64 @@ def make_encoder():
     print("encoder fixture done; blob elems", blob.size, flush=True)
 
 
+def make_cross_encoder():
+    import torch
+    from transformers import BertConfig, BertForSequenceClassification
+    from rag_amd._capi import BertConfig as MiCfg
+    from rag_amd.encoder_weights import head_from_state_dict, pack_state_dict
+
+    torch.manual_seed(4321)
+    hf = BertConfig(vocab_size=300, hidden_size=128, num_hidden_layers=2, num_attention_heads=4,
+                    intermediate_size=256, max_position_embeddings=64, type_vocab_size=2,
+                    layer_norm_eps=1e-12, hidden_act="gelu", hidden_dropout_prob=0.0,
+                    attention_probs_dropout_prob=0.0, num_labels=1)
+    hf._attn_implementation = "eager"
+    model = BertForSequenceClassification(hf).eval()
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("bias"):
+                p.normal_(0.0, 0.05)
+            elif "LayerNorm.weight" in name:
+                p.normal_(1.0, 0.05)
+            else:
+                p.normal_(0.0, 0.08)
+    B, L = 12, 48
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(3, hf.vocab_size, (B, L), generator=g)
+    qlen = 9                                            # [CLS] query [SEP] | passage [SEP]
+    lens = [48, 48, 40, 33, 31, 26, 20, 17, 15, 12, 11, 10]
+    mask = torch.zeros((B, L), dtype=torch.long)
+    types = torch.zeros((B, L), dtype=torch.long)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+        types[b, qlen:n] = 1
+        ids[b, :qlen] = ids[0, :qlen]                   # the same query in every pair
+        ids[b, n:] = 0
+    with torch.no_grad():
+        logits = model(input_ids=ids, attention_mask=mask, token_type_ids=types).logits
+    cfg = MiCfg(vocab_size=hf.vocab_size, hidden_size=hf.hidden_size, num_hidden_layers=hf.num_hidden_layers,
+                num_attention_heads=hf.num_attention_heads, intermediate_size=hf.intermediate_size,
+                max_position_embeddings=hf.max_position_embeddings, type_vocab_size=hf.type_vocab_size,
+                layer_norm_eps=hf.layer_norm_eps, normalize=0)
+    sd = model.state_dict()
+    blob = pack_state_dict(sd, cfg)
+    pw, pb, cw, cb = head_from_state_dict(sd, cfg)
+    np.savez_compressed(
+        os.path.join(HERE, "cross_encoder_small.npz"),
+        config=np.array([hf.vocab_size, hf.hidden_size, hf.num_hidden_layers, hf.num_attention_heads,
+                         hf.intermediate_size, hf.max_position_embeddings, hf.type_vocab_size], dtype=np.int64),
+        layer_norm_eps=np.float64(hf.layer_norm_eps), blob=blob.astype(np.float32),
+        pooler_w=pw, pooler_b=pb, cls_w=cw, cls_b=cb,
+        ids=ids.numpy().astype(np.int32), types=types.numpy().astype(np.int32), mask=mask.numpy().astype(np.int32),
+        logits=logits.numpy().astype(np.float32))
+    print("cross-encoder fixture done; logits", logits.numpy().ravel()[:4], flush=True)
+
+
 if __name__ == "__main__":
-    make_encoder()
-    make_search()
+    which = sys.argv[1:] or ["encoder", "search", "cross"]
+    if "encoder" in which:
+        make_encoder()
+    if "cross" in which:
+        make_cross_encoder()
+    if "search" in which:
+        make_search()

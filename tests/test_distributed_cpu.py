@@ -68,6 +68,54 @@ def test_two_rank_sharded_search_equals_single_index(tmp_path, oracle_mod, metri
             np.testing.assert_array_equal(D.view(np.uint32), Dw.view(np.uint32))
 
 
+def _embed_worker(rank, world, port, n, gather, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import oracle
+    from rag_amd.distributed import embed_sharded, shard_range
+    from tests._fakes import OracleEncoder
+    from tests.test_distributed_cpu import _embed_inputs
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg, blob, flat, offsets = _embed_inputs(oracle, n)
+        enc = OracleEncoder(cfg, blob)
+        E = embed_sharded(enc, flat, offsets, gather=gather, max_len=12)
+        lo, hi = shard_range(n, world, rank)
+        assert E.shape == ((n if gather else hi - lo), cfg.hidden_size) and enc.calls == (1 if hi > lo else 0)
+        np.save(os.path.join(out_dir, f"E_{rank}.npy"), E)
+    finally:
+        dist.destroy_process_group()
+
+
+def _embed_inputs(oracle, n):
+    from rag_amd._capi import BertConfig
+    from rag_amd.encoder_weights import random_blob
+    vals = (50, 32, 1, 2, 64, 16, 2, 1e-12, 1)
+    blob = random_blob(BertConfig(*vals), seed=2, init_range=0.2)
+    rng = np.random.default_rng(9)
+    lens = rng.integers(0, 15, size=n)                     # empty sequences and ones beyond max_len = 12 included
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat = rng.integers(0, 50, size=int(offsets[-1])).astype(np.int32)
+    return oracle.BertConfig(*vals), blob, flat, offsets
+
+
+@pytest.mark.parametrize("n,gather", [(11, True), (11, False), (1, True)])
+def test_two_rank_sharded_embedding_equals_single_rank(tmp_path, oracle_mod, n, gather):
+    """embed_sharded: contiguous chunk ranges per rank, no collective on the path, optional all-gather of the
+    [n][hidden] result (BASELINE config 3's data-parallel split), against one rank encoding everything."""
+    import torch.multiprocessing as mp
+    from rag_amd.distributed import shard_range
+    from tests._fakes import OracleEncoder
+    mp.spawn(_embed_worker, args=(2, _free_port(), n, gather, str(tmp_path)), nprocs=2, join=True)
+    cfg, blob, flat, offsets = _embed_inputs(oracle_mod, n)
+    want = OracleEncoder(cfg, blob).encode_ragged(flat, offsets, max_len=12)
+    for rank in (0, 1):
+        E = np.load(tmp_path / f"E_{rank}.npy")
+        lo, hi = shard_range(n, 2, rank)
+        np.testing.assert_array_equal(E, want if gather else want[lo:hi])
+
+
 def test_shard_ranges_partition_the_rows():
     from rag_amd.distributed import shard_range
     for n in (0, 1, 7, 100, 100_000_001):

@@ -1,0 +1,140 @@
+"""GPU: bulk embedding through the boundary the application calls (advanced_rag.py:295, FAISS.from_documents ->
+embed_documents): ragged token-budget batching inside the library (mi_encoder_encode_ragged), the kernel family a
+bulk call takes, and thread safety of one encoder shared by many host threads.  Bar: 1 - cosine <= 1e-3 against
+the CPU oracle on the same token ids (BASELINE.json north_star)."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _cos_err(a, b):
+    return 1.0 - (a * b).sum(1) / np.maximum(np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1), 1e-30)
+
+
+def _oracle_rows(oracle, ocfg, blob, flat, offsets, rows, max_len=0):
+    out = []
+    for i in rows:
+        ids = flat[offsets[i]:offsets[i + 1]]
+        if max_len:
+            ids = ids[:max_len]
+        out.append(oracle.encode(ocfg, blob, ids[None, :].astype(np.int32), np.ones((1, ids.size), dtype=np.int32))[0])
+    return np.stack(out)
+
+
+def test_ragged_entry_point_matches_oracle_in_input_order(oracle_mod):
+    """Lengths 0 .. beyond max_len in shuffled order: results come back in input order, an empty sequence is the
+    zero vector, long ones are truncated; small budget via max_batch so several passes and both staging sets run."""
+    from rag_amd._capi import BertConfig
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import random_blob
+    vals = (500, 128, 2, 4, 256, 64, 2, 1e-12, 1)
+    cfg, ocfg = BertConfig(*vals), oracle_mod.BertConfig(*vals)
+    blob = random_blob(cfg, seed=4, init_range=0.1)
+    rng = np.random.default_rng(3)
+    n = 57
+    lens = rng.integers(1, 80, size=n)
+    lens[5] = 0
+    lens[20] = 64
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat = rng.integers(0, 500, size=int(offsets[-1])).astype(np.int32)
+    enc = Encoder(cfg, blob)
+    for max_batch in (0, 7):
+        E = enc.encode_ragged(flat, offsets, max_len=60, max_batch=max_batch)
+        assert E.shape == (n, 128) and np.all(E[5] == 0)
+        rows = [i for i in range(n) if i != 5]
+        Eo = _oracle_rows(oracle_mod, ocfg, blob, flat, offsets, rows, max_len=60)
+        assert np.all(_cos_err(E[rows], Eo) < TOL)
+    st = enc.stats()
+    assert st["sequences"] == 2 * n and st["latency_passes"] >= 1 + 9
+    # the padded [B][L] entry point gives the same vectors (padding changes nothing)
+    L = 60
+    ids = np.zeros((n, L), dtype=np.int32)
+    mask = np.zeros((n, L), dtype=np.int32)
+    for i in range(n):
+        m = min(int(lens[i]), L)
+        ids[i, :m] = flat[offsets[i]:offsets[i] + m]
+        mask[i, :m] = 1
+    Ep = enc.encode_ids(ids, mask)
+    assert np.all(_cos_err(E[rows], Ep[rows]) < 1e-5)
+    from rag_amd import MI355Error
+    bad = flat.copy()
+    bad[3] = 500
+    with pytest.raises(MI355Error):
+        enc.encode_ragged(bad, offsets)
+
+
+def test_from_documents_of_2000_chunks_runs_the_bulk_kernels(tmp_path, oracle_mod):
+    """FAISS.from_documents on 2,000 chunks (advanced_rag.py:295): the embed call is cut by the library's token
+    budget, so every pass has >= 12,288 tokens and runs the fused bulk kernels (mi_encoder_stats), and the stored
+    rows equal the per-chunk oracle embeddings within 1e-3."""
+    from rag_amd import FAISS, Document, HuggingFaceEmbeddings
+    from rag_amd._capi import BertConfig
+    from rag_amd.encoder_weights import load_local_dir
+    from tests.test_retrievers import _write_model_dir
+    words = ["the", "cat", "sat", "on", "mat", "dogs", "chase", "red", "was", "flat", "index", "row"]
+    _write_model_dir(str(tmp_path / "m"), hidden=384, layers=2, heads=12, inter=1536)
+    emb = HuggingFaceEmbeddings(model_name=str(tmp_path / "m"), model_kwargs={"device": 0}, max_seq_length=64)
+    rng = np.random.default_rng(1)
+    texts = [" ".join(rng.choice(words, size=int(rng.integers(8, 61)))) for _ in range(2000)]
+    vs = FAISS.from_documents([Document(page_content=t, metadata={"i": i}) for i, t in enumerate(texts)], emb)
+    st = emb.encoder.stats()
+    assert st["sequences"] == 2000 and st["bulk_passes"] >= 1 and st["latency_passes"] == 0, st
+    assert st["tokens"] >= 12288 * st["bulk_passes"]
+    E = vs.index.reconstruct_n(0, 2000)
+    toks = emb._tokenize(texts)
+    flat, offsets = emb._to_csr(toks)
+    _, blob = load_local_dir(str(tmp_path / "m"))
+    ocfg = oracle_mod.BertConfig(*[getattr(emb.encoder.cfg, f) for f, _ in BertConfig._fields_])
+    rows = list(range(0, 2000, 8))
+    Eo = _oracle_rows(oracle_mod, ocfg, blob, flat, offsets, rows)
+    err = _cos_err(E[rows], Eo)
+    assert np.all(err < TOL), err.max()
+    # a caller that sets batch_size gets its cap (sentence-transformers' semantics): 32 rows per pass -> latency kernels
+    emb32 = HuggingFaceEmbeddings(model_name=str(tmp_path / "m"), model_kwargs={"device": 0}, encode_kwargs={"batch_size": 32},
+                                  max_seq_length=64)
+    E32 = emb32.embed_documents_array(texts[:100])
+    assert emb32.encoder.stats()["latency_passes"] == 4 and np.all(_cos_err(E32, E[:100]) < 1e-4)
+
+
+def test_one_encoder_shared_by_eight_threads(oracle_mod):
+    """LangChain's RunnableParallel workers and Gradio handlers call embed_query / embed_documents on ONE
+    embeddings object (advanced_rag.py:302-305, 545-555).  Eight threads encode different batches through the
+    host-pointer and the ragged entry points at once; every result equals the single-threaded one bit for bit."""
+    from rag_amd._capi import BertConfig
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import random_blob
+    cfg = BertConfig(1000, 384, 2, 12, 1536, 512, 2, 1e-12, 1)
+    enc = Encoder(cfg, random_blob(cfg, seed=8, init_range=0.05))
+    rng = np.random.default_rng(5)
+    jobs = []
+    for t in range(8):
+        B, L = int(rng.integers(1, 9)), int(rng.integers(4, 90))
+        ids = rng.integers(0, 1000, size=(B, L)).astype(np.int32)
+        mask = np.ones((B, L), dtype=np.int32)
+        mask[0, L // 2:] = 0
+        lens = rng.integers(1, 70, size=B + 3)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        flat = rng.integers(0, 1000, size=int(off[-1])).astype(np.int32)
+        jobs.append((ids, mask, flat, off))
+    want = [(enc.encode_ids(i, m), enc.encode_ragged(f, o)) for i, m, f, o in jobs]
+    errors = []
+
+    def work(t):
+        try:
+            ids, mask, flat, off = jobs[t]
+            for it in range(12):
+                a = enc.encode_ids(ids, mask)
+                b = enc.encode_ragged(flat, off)
+                if not (np.array_equal(a, want[t][0]) and np.array_equal(b, want[t][1])):
+                    errors.append((t, it))
+        except Exception as e:          # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errors, errors[:3]

@@ -22,7 +22,7 @@ def kernel_family(request, monkeypatch):
     if request.param == "bulk":
         monkeypatch.setenv("MI_ENC_LATENCY_TOKENS", "0")
     else:
-        monkeypatch.delenv("MI_ENC_LATENCY_TOKENS", raising=False)
+        monkeypatch.setenv("MI_ENC_LATENCY_TOKENS", "1000000000")
     return request.param
 
 

@@ -71,3 +71,23 @@ def test_bad_token_id_is_rejected(oracle_mod):
     ids[0, 0] = 10**6
     with pytest.raises(ValueError):
         oracle_mod.encode(cfg, g["blob"], ids, g["mask"][:1])
+
+
+XGOLD = os.path.join(os.path.dirname(__file__), "golden", "cross_encoder_small.npz")
+
+
+def test_oracle_classify_matches_sequence_classification_fixture(oracle_mod):
+    """Cross-encoder head (token type ids + BertPooler + classifier) against the committed
+    transformers.BertForSequenceClassification fixture (tests/golden/make_golden.py cross)."""
+    g = np.load(XGOLD)
+    c = [int(v) for v in g["config"]]
+    cfg = oracle_mod.BertConfig(c[0], c[1], c[2], c[3], c[4], c[5], c[6], float(g["layer_norm_eps"]), 0)
+    head = (g["pooler_w"], g["pooler_b"], g["cls_w"], g["cls_b"])
+    got = oracle_mod.classify(cfg, g["blob"], head, g["ids"], g["types"], g["mask"])
+    assert got.shape == g["logits"].shape
+    assert np.abs(got - g["logits"]).max() < 5e-5
+    # the type ids matter: all-zero types give different logits
+    other = oracle_mod.classify(cfg, g["blob"], head, g["ids"], None, g["mask"])
+    assert np.abs(other - g["logits"]).max() > 1e-3
+    with pytest.raises(ValueError):
+        oracle_mod.classify(cfg, g["blob"], head, g["ids"], g["types"] + 5, g["mask"])

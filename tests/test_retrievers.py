@@ -108,7 +108,7 @@ def test_save_and_load_local_round_trip(tmp_path, dtype):
 
 
 def _write_model_dir(path, hidden=128, layers=1, heads=4, inter=128, vocab_words=("[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]",
-                     "the", "cat", "sat", "on", "mat", "dogs", "chase", "##s", "red", "was", "flat", "index", "row")):
+                     "the", "cat", "sat", "on", "mat", "dogs", "chase", "##s", "red", "was", "flat", "index", "row"), head_labels=0):
     from safetensors.numpy import save_file
     from rag_amd._capi import BertConfig
     from rag_amd.encoder_weights import random_blob
@@ -134,7 +134,17 @@ def _write_model_dir(path, hidden=128, layers=1, heads=4, inter=128, vocab_words
             sd[p + nm + ".weight"] = np.ones(H)
             sd[p + nm + ".bias"] = np.zeros(H)
     # sentence-transformers checkpoints prefix the names; the loader strips it
-    save_file({"bert." + k: np.ascontiguousarray(v, dtype=np.float32) for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    out = {"bert." + k: np.ascontiguousarray(v, dtype=np.float32) for k, v in sd.items()}
+    if head_labels:                                   # a BertForSequenceClassification checkpoint (cross-encoder)
+        sd["pooler.dense.weight"] = rng.standard_normal((H, H)) * 0.05
+        sd["pooler.dense.bias"] = rng.standard_normal(H) * 0.05
+        sd["classifier.weight"] = rng.standard_normal((head_labels, H)) * 0.2
+        sd["classifier.bias"] = rng.standard_normal(head_labels) * 0.05
+        out["bert.pooler.dense.weight"] = sd["pooler.dense.weight"].astype(np.float32)
+        out["bert.pooler.dense.bias"] = sd["pooler.dense.bias"].astype(np.float32)
+        out["classifier.weight"] = sd["classifier.weight"].astype(np.float32)
+        out["classifier.bias"] = sd["classifier.bias"].astype(np.float32)
+    save_file(out, os.path.join(path, "model.safetensors"))
     return cfgd, sd
 
 
