@@ -219,6 +219,14 @@ int  mi_encoder_classify_dev(mi_encoder* enc, int64_t B, int L, const int32_t* i
  * out[2] passes that ran the bulk kernel family (fused per-tile kernels, >= 12,288 tokens),
  * out[3] passes that ran the latency family (general GEMMs). */
 int  mi_encoder_stats(const mi_encoder* enc, int64_t out[4]);
+/* Allocation-free variant of mi_encoder_encode_dev.  No counterpart in the reference; it is for callers that
+ * cannot allocate: code under HIP graph capture, tight serving loops that embed one query per call, harnesses
+ * that forbid hipMalloc.  Same kernels and results; the activation workspace comes from a 16-MiB file-scope
+ * device array of the library (one per GPU, held until the process ends) instead of hipMalloc, and the call
+ * makes no hipMalloc / hipFree.  Inputs whose workspace does not fit (MiniLM-L6: more than ~2,000 tokens)
+ * fail with MI_ERR_UNSUPPORTED.  All calls on one GPU share that array: calls that overlap on one GPU race. */
+int  mi_encoder_encode_dev_noalloc(mi_encoder* enc, int64_t B, int L, const int32_t* ids_dev,
+                                   const int32_t* mask_dev, float* out_emb_dev, void* stream);
 /* Timing of the last encode pass (all kernels), HIP events on its stream. */
 int  mi_encoder_last_time(const mi_encoder* enc, float* out_ms);
 

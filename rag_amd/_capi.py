@@ -73,6 +73,7 @@ SYMBOLS = {
     "mi_encoder_destroy": (None, [_vp]),
     "mi_encoder_encode": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "mi_encoder_encode_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "mi_encoder_encode_dev_noalloc": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "mi_encoder_encode_ragged": (_i32, [_vp, _i64, _vp, _vp, _i32, _i32, _vp]),
     "mi_encoder_set_head": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32]),
     "mi_encoder_classify": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),

@@ -1407,6 +1407,32 @@ __global__ __launch_bounds__(256) void cls_head_kernel(const uint16_t* __restric
 }
 
 // ================================================================ host side
+// Activation workspace of the allocation-free entry point (mi_encoder_encode_dev_noalloc): callers that cannot
+// call hipMalloc -- code under HIP graph capture, tight serving loops that embed one query at a time -- get the
+// encoder's per-pass workspace from this array instead of the grow-only hipMalloc'd one.  One copy per GPU the
+// library runs on, held until the process ends.  `scratch` is a host-side stand-in here, not a device address:
+// host code only ever uses the pointer hipGetSymbolAddress returned for the current device (g_scratch_ptr).
+#define MI_ENC_NOALLOC_BYTES ((size_t)16 << 20)
+static __device__ __align__(256) unsigned char scratch[MI_ENC_NOALLOC_BYTES];
+#define MI_MAX_DEVICES 64
+static void* g_scratch_ptr[MI_MAX_DEVICES];          // per device: each GPU holds its own copy at its own address
+static std::mutex g_scratch_mu;
+
+// Once per device, with that device current (mi_encoder_create, the encoder's init call).
+static int scratch_for_device(int device, void** out)
+{
+    if (device < 0 || device >= MI_MAX_DEVICES) { mi_set_error("encoder: device %d beyond the %d this build keeps scratch pointers for", device, MI_MAX_DEVICES); return MI_ERR_UNSUPPORTED; }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        hipError_t er = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (er != hipSuccess || !ptr) { mi_set_error("encoder: hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(er)); return MI_ERR_HIP; }
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return MI_OK;
+}
+
 struct LayerW {
     uint16_t *Wqkv, *Wo, *Wi, *Wd;                 // bf16 [out][in]
     uint16_t *Wi_p = nullptr;                      // [I / 32][12][32][32] swizzled LDS image of Wi blocks (ffn_ln_kernel)
@@ -1456,6 +1482,8 @@ struct mi_encoder {
     int nlabels = 0;
     // counters since creation: sequences, padded tokens, passes on the bulk / on the latency kernel family
     int64_t st_seqs = 0, st_tokens = 0, st_bulk = 0, st_latency = 0;
+    // this device's address of the file-scope `scratch` array (mi_encoder_encode_dev_noalloc)
+    void* scratch_dev = nullptr;
 };
 
 extern "C" int64_t mi_encoder_blob_elems(const mi_bert_config* c)
@@ -1506,6 +1534,7 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
     e->cfg = *cfg;
     auto fail = [&](int code) { encoder_free(e); return code; };
 #define ENC_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { mi_set_error("%s failed: %s", #call, hipGetErrorString(_e)); return fail(_e == hipErrorOutOfMemory ? MI_ERR_OOM : MI_ERR_HIP); } } while (0)
+    { const int src = scratch_for_device(device, &e->scratch_dev); if (src != MI_OK) return fail(src); }
     ENC_HIP(hipMalloc((void**)&e->blob, (size_t)want * sizeof(float)));
     ENC_HIP(hipMemcpyAsync(e->blob, blob_host, (size_t)want * sizeof(float), hipMemcpyHostToDevice, e->stream));
     const int64_t per_layer_w = (int64_t)4 * H * H + 2 * (int64_t)I * H + ((int64_t)H * H + 2 * (int64_t)H * I);   // + packed Wo, Wd, Wi
@@ -1802,6 +1831,32 @@ extern "C" int mi_encoder_encode_dev(mi_encoder* e, int64_t B, int L, const int3
     std::lock_guard<std::mutex> lk(e->mu);
     DeviceGuard guard(e->device);
     return encode_dev_locked(e, B, L, ids_dev, nullptr, mask_dev, out_emb_dev, nullptr, mi_pick_stream(stream, e->stream));
+}
+
+// The allocation-free variant of mi_encoder_encode_dev: the same kernels, the activation workspace taken from the
+// file-scope `scratch` array of this device instead of hipMalloc.  One pass; inputs whose workspace exceeds
+// MI_ENC_NOALLOC_BYTES are rejected.  Nothing in the workspace has to start at zero (every kernel writes what a
+// later one reads; rows past the last token are read as padding of whole tiles and never stored), so nothing is
+// cleared.  Every call on a GPU uses that GPU's one array: calls that overlap on one GPU -- two encoders, or one
+// encoder on two streams -- race; serialise them.
+extern "C" int mi_encoder_encode_dev_noalloc(mi_encoder* e, int64_t B, int L, const int32_t* ids_dev, const int32_t* mask_dev,
+                                             float* out_emb_dev, void* stream)
+{
+    MI_REQUIRE(e && B >= 0 && L > 0, "mi_encoder_encode_dev_noalloc: bad argument");
+    MI_REQUIRE(L <= e->cfg.max_position_embeddings, "mi_encoder_encode_dev_noalloc: L=%d exceeds max_position_embeddings=%d", L, e->cfg.max_position_embeddings);
+    if (B == 0) return MI_OK;
+    MI_REQUIRE(ids_dev && mask_dev && out_emb_dev, "mi_encoder_encode_dev_noalloc: NULL buffer");
+    MI_REQUIRE(B <= ((int64_t)1 << 20), "mi_encoder_encode_dev_noalloc: B=%lld out of range", (long long)B);
+    const size_t need = encoder_ws_need(e->cfg, B * L);
+    if (need > MI_ENC_NOALLOC_BYTES) {
+        mi_set_error("mi_encoder_encode_dev_noalloc: %lld tokens need %zu bytes of workspace; this entry point holds %zu "
+                     "(use mi_encoder_encode_dev for larger batches)", (long long)(B * L), need, (size_t)MI_ENC_NOALLOC_BYTES);
+        return MI_ERR_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard guard(e->device);
+    return encode_pass_locked(e, B, L, ids_dev, nullptr, mask_dev, out_emb_dev, nullptr, mi_pick_stream(stream, e->stream),
+                              e->scratch_dev, MI_ENC_NOALLOC_BYTES);
 }
 
 extern "C" int mi_encoder_classify_dev(mi_encoder* e, int64_t B, int L, const int32_t* ids_dev, const int32_t* type_ids_dev,

@@ -73,6 +73,18 @@ class Encoder:
                                                     stream))
         return out
 
+    def encode_ids_torch_noalloc(self, ids, mask, out=None):
+        """As encode_ids_torch through mi_encoder_encode_dev_noalloc: no hipMalloc inside the library (small batches
+        only; the caller may pass `out` so that nothing at all is allocated around the call)."""
+        import torch
+        B, L = ids.shape
+        if out is None:
+            out = torch.empty((B, self.hidden_size), dtype=torch.float32, device=ids.device)
+        _capi.check(self._lib.mi_encoder_encode_dev_noalloc(self._h, B, L, ctypes.c_void_p(ids.data_ptr()),
+                                                            ctypes.c_void_p(mask.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                                            _capi.stream_arg(ids.device)))
+        return out
+
     def encode_ragged(self, flat_ids: np.ndarray, offsets: np.ndarray, max_len: int = 0, max_batch: int = 0) -> np.ndarray:
         """n ragged sequences (CSR: flat token ids + offsets [n + 1]) -> [n][hidden], input order.  Length-sorted,
         token-budget batching and pinned double-buffered staging happen inside the library (mi_encoder_encode_ragged)."""
