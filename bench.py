@@ -9,8 +9,8 @@ resident in HBM.  `python bench.py --gpus N --steps K --warmup W`; for N > 1 lau
 torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
 
 Strong scaling: the corpus size is fixed (the metric is quoted at 100M rows), each of the N
-ranks holds rows [r*N/G, (r+1)*N/G).  The only exchange step is the all-gather of the
-per-rank (score, id) lists, Q*k*12 bytes per rank.
+ranks holds rows [r*N/G, (r+1)*N/G).  The only exchange step is ONE all-gather of the
+per-rank packed (score, id) blocks, Q*k*12 bytes per rank (rag_amd.distributed).
 """
 from __future__ import annotations
 
@@ -34,54 +34,112 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def pmc_traffic(rows_per_gpu, dim, dtype, queries):
-    """HBM-side bytes per scan launch from the committed rocprofv3 PMC pass (profiles/scan_traffic.json;
-    counters cannot be read from inside the timed process), or None when no pass covers this case."""
+def _sha256(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def pmc_traffic(name, **case):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC pass (profiles/scan_traffic.json; counters cannot be
+    read from inside the timed process).  The file records the SHA-256 of the kernel source each pass was taken at:
+    when the source in this tree differs, the number describes another build and None is returned."""
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "scan_traffic.json")) as f:
-            for c in json.load(f)["cases"]:
-                if (c["rows_per_gpu"], c["dim"], c["dtype"], c["queries"]) == (rows_per_gpu, dim, dtype, queries):
-                    return c["traffic_GB_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "scan_traffic.json")) as f:
+            doc = json.load(f)
+        sec = doc[name]
+        if _sha256(os.path.join(ROOT, sec["kernel_source"])) != sec["kernel_source_sha256"]:
+            return None
+        for c in sec["cases"]:
+            if all(c.get(k) == v for k, v in case.items()):
+                return c["traffic_GB_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
     return None
 
 
 def bench_embed(args, dev, rank, world, barrier):
-    """Second half of BASELINE.json's metric: chunks/s, bulk embedding of 256-token chunks with a
-    MiniLM-L6 encoder (seeded random weights, synthetic token ids), data-parallel, no collective."""
+    """Second half of BASELINE.json's metric: chunks/s, bulk embedding of 256-token chunks with a MiniLM-L6 encoder
+    (seeded random weights, synthetic token ids), data-parallel, no collective.  Three measurements:
+      value     ids and mask resident in HBM, all-ones mask (the peak)
+      via_api   the same chunks from HOST token ids to HOST embeddings through mi_encoder_encode_ragged, the call
+                MI355Embeddings.embed_tokenized / embed_documents_array makes (FAISS.from_documents, advanced_rag.py:295)
+      ragged    lengths uniform in [32, 256] through the same call (the realistic mix)"""
     from rag_amd.embeddings import Encoder
     from rag_amd.encoder_weights import minilm_l6_config, random_blob
     cfg = minilm_l6_config()
     blob = random_blob(cfg, seed=0, init_range=0.02)
     enc = Encoder(cfg, blob, device=dev.index)
     B, L = args.embed_chunks, 256
+    H, I, nl = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    ids = torch.randint(1000, 30000, (B, L), generator=g, dtype=torch.int32).to(dev)
+    ids_h = torch.randint(1000, 30000, (B, L), generator=g, dtype=torch.int32)
+    ids = ids_h.to(dev)
     mask = torch.ones((B, L), dtype=torch.int32, device=dev)
     enc.encode_ids_torch(ids[:256], mask[:256])          # warm-up
-    barrier()
-    t0 = time.perf_counter()
-    ms = 0.0
-    for _ in range(args.embed_steps):
-        E = enc.encode_ids_torch(ids, mask)
-    barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+
+    def timed(fn, steps):
+        barrier()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            out = fn()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    def flops(lens):                                     # algorithmic: per token 8 h^2 + 4 h f + 4 L h, per layer
+        lens = np.asarray(lens, dtype=np.float64)
+        return float(nl * np.sum(lens * (8.0 * H * H + 4.0 * H * I + 4.0 * lens * H)))
+
+    def roof(fl, el):
+        ach = fl / el / 1e12
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4)}
+
+    el, E = timed(lambda: enc.encode_ids_torch(ids, mask), args.embed_steps)
     chunks = B * args.embed_steps * world
-    H, I, nl = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
-    flop_chunk = nl * L * (8 * H * H + 4 * H * I + 4 * L * H)        # SURVEY.md §8d: 6.04 GFLOP
+    rl = roof(flops([L] * B) * args.embed_steps, el)
+    rl.update({"traffic": pmc_traffic("encoder", chunks=B, tokens=L),
+               "note": "whole encoder forward (all kernels), algorithmic 6.04 GFLOP per chunk; traffic = FETCH + WRITE bytes "
+                       "per 4096-chunk call from the committed PMC pass (GB), null when encoder.hip changed since"})
     res = {"metric": "chunks/s embed (256-token chunks, MiniLM-L6, bf16 MFMA)", "value": round(chunks / el, 1),
-           "unit": "chunks/s", "chunks_per_step_per_gpu": B, "steps": args.embed_steps,
-           "roofline": {"bound": "mfma", "achieved": round(chunks / el * flop_chunk / 1e12 / world, 2),
-                        "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(chunks / el * flop_chunk / 1e12 / world / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                        "note": "whole encoder forward (all kernels), algorithmic 6.04 GFLOP per chunk"},
-           "cpu_baseline": None}
+           "unit": "chunks/s", "chunks_per_step_per_gpu": B, "steps": args.embed_steps, "roofline": rl, "cpu_baseline": None}
+
+    # ---- through the boundary the application calls: host CSR token ids in, host embeddings out
+    flat = ids_h.numpy().reshape(-1)
+    offsets = np.arange(B + 1, dtype=np.int64) * L
+    enc.encode_ragged(flat[:64 * L], offsets[:65], max_len=256)
+    st0 = enc.stats()
+    el_api, E_api = timed(lambda: enc.encode_ragged(flat, offsets, max_len=256), args.embed_steps)
+    st1 = enc.stats()
+    res["via_api"] = {"value": round(chunks / el_api, 1), "unit": "chunks/s", "frac_of_resident": round(el / el_api, 4),
+                      "bulk_passes": st1["bulk_passes"] - st0["bulk_passes"], "latency_passes": st1["latency_passes"] - st0["latency_passes"],
+                      "path": "host int32 token ids (CSR) -> mi_encoder_encode_ragged -> host fp32 embeddings; PCIe both ways, "
+                              "length sort, token-budget passes and pinned staging inside the timed region",
+                      "max_abs_diff_vs_resident": float(np.abs(E_api - E.cpu().numpy()).max())}
+
+    # ---- ragged mix: lengths uniform in [32, 256] (SURVEY.md section 8d)
+    rng = np.random.default_rng(77 + rank)
+    lens = rng.integers(32, 257, size=B)
+    roff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    rflat = rng.integers(1000, 30000, size=int(roff[-1])).astype(np.int32)
+    enc.encode_ragged(rflat[:roff[64]], roff[:65], max_len=256)
+    st0 = enc.stats()
+    el_r, _ = timed(lambda: enc.encode_ragged(rflat, roff, max_len=256), args.embed_steps)
+    st1 = enc.stats()
+    real_tok = int(lens.sum()) * args.embed_steps
+    res["ragged"] = {"value": round(chunks / el_r, 1), "unit": "chunks/s", "lengths": "uniform in [32, 256], mean %.1f" % lens.mean(),
+                     "tokens_per_s": round(real_tok * world / el_r, 1),
+                     "padding_overhead": round((st1["tokens"] - st0["tokens"]) / real_tok - 1.0, 4),
+                     "bulk_passes": st1["bulk_passes"] - st0["bulk_passes"], "latency_passes": st1["latency_passes"] - st0["latency_passes"],
+                     "roofline": roof(flops(lens) * args.embed_steps, el_r)}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         ocfg = oracle.BertConfig(*[getattr(cfg, f) for f, _ in type(cfg)._fields_])
@@ -110,6 +168,8 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
     ap.add_argument("--cpu-queries", type=int, default=4096)
+    ap.add_argument("--blas-rows", type=int, default=500_000, help="rows of the sgemm + argpartition CPU leg")
+    ap.add_argument("--blas-queries", type=int, default=1024)
     ap.add_argument("--check", type=int, default=8, help="queries verified against the oracle on the CPU sample rows")
     ap.add_argument("--embed-chunks", type=int, default=4096, help="256-token chunks per rank per embed step (0 = skip)")
     ap.add_argument("--embed-steps", type=int, default=3)
@@ -128,7 +188,8 @@ def main() -> int:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from rag_amd.index import FlatIndex, topk_merge_torch
+    from rag_amd.distributed import ShardedFlatIndex
+    from rag_amd.index import FlatIndex
 
     def barrier():
         if world > 1:
@@ -164,16 +225,13 @@ def main() -> int:
 
     scan_ms, scan_launches = [], []
 
+    # rank-local search into the rank's packed block, ONE all-gather of the blocks, merge in place
+    sharded = ShardedFlatIndex(d, metric="ip", dtype=args.dtype, device=local_rank, local_index=idx) if world > 1 else None
+
     def step():
-        D, I = idx.search_torch(q_dev, k)
         if world > 1:
-            Dg = torch.empty((world * Q, k), dtype=D.dtype, device=dev)      # rank-major concat
-            Ig = torch.empty((world * Q, k), dtype=I.dtype, device=dev)
-            dist.all_gather_into_tensor(Dg, D)
-            dist.all_gather_into_tensor(Ig, I)
-            D, I = topk_merge_torch(Dg.view(world, Q, k).permute(1, 0, 2).reshape(Q, world * k),
-                                    Ig.view(world, Q, k).permute(1, 0, 2).reshape(Q, world * k), k, "ip")
-        return D, I
+            return sharded.search_torch(q_dev, k)
+        return idx.search_torch(q_dev, k)
 
     for _ in range(args.warmup):
         step()
@@ -210,11 +268,9 @@ def main() -> int:
         regimes.append({"queries": Qs, "scan_ms": round(m, 3), "achieved_GBs": round(gbs, 1),
                         "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "qps_per_gpu": round(Qs / (m * 1e-3), 1),
                         "algorithmic_GB": round(float(nloc) * d * (2 if args.dtype == "bf16" else 4) / 1e9, 2),
-                        "traffic_GB": pmc_traffic(nloc, d, args.dtype, Qs)})
+                        "traffic_GB": pmc_traffic("scan", rows_per_gpu=nloc, dim=d, dtype=args.dtype, queries=Qs)})
     embed = None
     if args.embed_chunks > 0:
-        nloc_keep = nloc
-        D_keep, I_keep = D, I
         embed = bench_embed(args, dev, rank, world, barrier)
 
     if rank != 0:
@@ -233,8 +289,8 @@ def main() -> int:
     if kind == "mfma_bf16":
         ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(nloc, d, args.dtype, Q),
-                    "traffic_unit": "GB per launch (FETCH_SIZE PMC pass, profiles/r01_scan_pmc_v5.md)",
+                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic("scan", rows_per_gpu=nloc, dim=d, dtype=args.dtype, queries=Q),
+                    "traffic_unit": "GB per launch (FETCH_SIZE PMC pass, profiles/scan_traffic.json; null when the kernel source changed since)",
                     "kernel": "mfma_scan_kernel", "avg_launch_ms": round(avg_ms, 3),
                     "algorithmic_hbm_GBs": round(bytes_per_launch / (avg_ms * 1e-3) / 1e9, 1)}
     else:
@@ -243,7 +299,10 @@ def main() -> int:
                     "frac": round(ach / 157.3, 4), "traffic": None, "kernel": "scan_dense_kernel",
                     "avg_launch_ms": round(avg_ms, 3)}
 
-    # ---- CPU baseline (the oracle = CPU port of the reference's flat search), bounded sample
+    # ---- CPU baseline, bounded samples of the same workload, two legs:
+    #   port       the oracle: AVX2 fmaf-chain restatement of IndexFlat::search (bit-exact with the GPU path)
+    #   port-blas  what faiss does for nq >= 20 and what SURVEY.md section 8d planned: blocked fp32 sgemm (NumPy/BLAS)
+    #              + argpartition + sort of the k winners; its summation order is the BLAS's, so it is timed, not compared
     cpu = None
     check = None
     if not args.no_cpu_baseline and ngpu == 1:
@@ -256,16 +315,45 @@ def main() -> int:
         tc = time.perf_counter()
         Do, Io = oracle.search(rows_in, q_host[:cq], k, metric=oracle.METRIC_IP, dtype=odt)
         tcpu = time.perf_counter() - tc
-        # extrapolate linearly in N to the full corpus (SURVEY.md §8d)
-        cpu_qps = cq / tcpu * (crow / float(N))
-        cpu = {"value": cpu_qps, "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
-               "sample": f"oracle.search (AVX2 fmaf-chain port of IndexFlat) on the first {crow} rows x {cq} queries "
-                         f"in {tcpu:.2f}s, extrapolated linearly in N to {N} rows"}
+        # extrapolate linearly in N to the full corpus (SURVEY.md section 8d)
+        port = {"value": cq / tcpu * (crow / float(N)), "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
+                "sample": f"oracle.search (AVX2 fmaf-chain port of IndexFlat) on the first {crow} rows x {cq} queries "
+                          f"in {tcpu:.2f}s, extrapolated linearly in N to {N} rows"}
         # parity spot check at bench size: the GPU answer restricted to the sample rows
         if args.check > 0 and crow == nloc:
             ok = bool(np.array_equal(I[:cq].cpu().numpy(), Io) and
                       np.array_equal(D[:cq].cpu().numpy().view(np.uint32), Do.view(np.uint32)))
             check = {"queries": cq, "bit_exact_vs_oracle": ok}
+        brow, bq = min(args.blas_rows, crow), min(args.blas_queries, Q)
+        qb = np.ascontiguousarray(q_host[:bq])
+        if args.dtype == "bf16":
+            qb = oracle.bf16_to_f32(oracle.round_bf16(qb))
+        tc = time.perf_counter()
+        best_s = np.full((bq, k), -np.inf, dtype=np.float32)
+        best_i = np.full((bq, k), -1, dtype=np.int64)
+        blk = 65536
+        for r0 in range(0, brow, blk):
+            S = qb @ rows[r0:r0 + blk].T                                      # sgemm, [bq][blk]
+            kk = min(k, S.shape[1])
+            part = np.argpartition(-S, kk - 1, axis=1)[:, :kk]
+            cand_s = np.concatenate([best_s, np.take_along_axis(S, part, axis=1)], axis=1)
+            cand_i = np.concatenate([best_i, part + r0], axis=1)
+            o = np.lexsort((cand_i, -cand_s), axis=1)[:, :k]
+            best_s, best_i = np.take_along_axis(cand_s, o, axis=1), np.take_along_axis(cand_i, o, axis=1)
+        tblas = time.perf_counter() - tc
+        try:
+            from threadpoolctl import threadpool_info
+            bthreads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+        except Exception:
+            bthreads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+        agree = float(np.mean(best_i[:min(bq, cq)] == Io[:min(bq, cq)])) if brow == crow else None
+        blas = {"value": bq / tblas * (brow / float(N)), "unit": "queries/s", "cores": bthreads, "kind": "port-blas",
+                "sample": f"NumPy sgemm + argpartition + sort on the first {brow} rows x {bq} queries in {tblas:.2f}s "
+                          f"(blocks of {blk} rows), extrapolated linearly in N to {N} rows",
+                "ids_equal_to_port": agree}
+        top = blas if blas["value"] > port["value"] else port
+        cpu = {"value": top["value"], "unit": "queries/s", "cores": top["cores"], "kind": "port",
+               "sample": top["sample"], "legs": [port, blas]}
 
     out = {
         "metric": "queries/sec exact top-10 @100Mx384 bf16",

@@ -123,6 +123,42 @@ class VectorStoreRetriever:
         return left | _runnable_lambda(self.invoke)
 
 
+_LC_RETRIEVER = None
+
+
+def _langchain_retriever_class():
+    """A `langchain_core.retrievers.BaseRetriever` subclass over the same store, when langchain_core is importable.
+    LangChain's own EnsembleRetriever (advanced_rag.py:19, :298) is a pydantic model whose `retrievers` field
+    validates its members as Runnables: the plain VectorStoreRetriever above composes with `|` but would be rejected
+    there, so with LangChain present `as_retriever` hands out this class instead (documents are converted to
+    langchain_core's Document).  NOT TESTED in this repository: langchain_core is absent from the build image and
+    the GPU box; without it, import BM25Retriever / EnsembleRetriever from rag_amd as well."""
+    global _LC_RETRIEVER
+    if _LC_RETRIEVER is not None:
+        return _LC_RETRIEVER or None
+    try:
+        from langchain_core.documents import Document as LCDocument  # type: ignore
+        from langchain_core.retrievers import BaseRetriever  # type: ignore
+    except Exception:
+        _LC_RETRIEVER = False
+        return None
+
+    class LangChainVectorStoreRetriever(BaseRetriever):  # pragma: no cover - needs langchain_core
+        vectorstore: Any
+        search_type: str = "similarity"
+        search_kwargs: dict = {}
+
+        class Config:
+            arbitrary_types_allowed = True
+
+        def _get_relevant_documents(self, query: str, *, run_manager: Any = None) -> List[Any]:
+            inner = VectorStoreRetriever(self.vectorstore, search_type=self.search_type, search_kwargs=self.search_kwargs)
+            return [LCDocument(page_content=d.page_content, metadata=d.metadata) for d in inner.get_relevant_documents(query)]
+
+    _LC_RETRIEVER = LangChainVectorStoreRetriever
+    return _LC_RETRIEVER
+
+
 class MI355VectorStore:
     """Flat exact vector store with the FAISS wrapper's constructor and methods."""
 
@@ -326,6 +362,10 @@ class MI355VectorStore:
     # ---- retriever
     def as_retriever(self, **kwargs: Any) -> VectorStoreRetriever:
         tags = (kwargs.pop("tags", None) or []) + [type(self).__name__]
+        lc = _langchain_retriever_class()
+        if lc is not None:                                  # LangChain present: a real BaseRetriever / Runnable
+            VectorStoreRetriever(self, tags=tags, **kwargs)   # same argument validation
+            return lc(vectorstore=self, tags=tags, **kwargs)
         return VectorStoreRetriever(self, tags=tags, **kwargs)
 
     # ---- persistence.  LangChain's save_local pickles the docstore; this
