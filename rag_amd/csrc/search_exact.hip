@@ -5,6 +5,7 @@
 //   merge       : per query, best k of up to 4096 (score,id) entries (segments, shards)
 // This is the ground-truth path: the MFMA scan (search_mfma.hip) falls back to it whenever
 // its certificate does not hold, and an F32 index uses it directly.
+#include <stdlib.h>
 #include "kernels.h"
 
 // ---------------------------------------------------------------- scan_dense
@@ -180,6 +181,136 @@ static void launch_scan_dense_small(hipStream_t st, const T* rows, int64_t row0,
     else scan_dense_small_kernel<T, 4><<<grid, 64, 0, st>>>(rows, row0, nrows, d_pad, q_canon, nq, S, s_stride);
 }
 
+// ---------------------------------------------------------------- scan_dense on the fp32 matrix pipe
+// The same numbers from v_mfma_f32_32x32x2_f32: its result is bit for bit the k-ordered fp32 fmaf chain
+// D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) -- one rounding per product, no wider accumulation, denormals kept
+// (cdna_hip_programming.md, "FP32-input MFMA") -- so chaining the instruction over k = 0, 2, 4, ... from C = +0
+// IS the canonical score, at the matrix pipe's 64 FLOP/clk/SIMD with one operand register per 2,048 FMAs instead
+// of the VALU kernel's LDS read per 4.  Held to bit equality with the oracle by tests/test_search_gpu.py.
+//
+// Workgroup = 4 waves = 256 rows x (32 NQB) queries; wave w owns rows 64 w .. 64 w + 63 as two 32-row blocks
+// (the B operand: lane l supplies row (l & 31), k = 2 t + (l >> 5)) against NQB 32-query blocks (the A operand),
+// so D[query][row]: a lane's column is a ROW and S[q][r .. r + 31] leaves as 128-byte segments.  Operands pass
+// through LDS in k-chunks of 32 (row stride 33 floats: the 32 lanes of a half-wave hit 32 banks), the next
+// chunk waits in registers while this one is multiplied.
+#define SM_ROWS 256
+#define SM_KC 32
+#define SM_LD 33
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T, int NQB>
+__global__ __launch_bounds__(256) void scan_dense_mfma_kernel(const T* __restrict__ rows, int64_t row0, int nrows,
+                                                              int d_pad, const float* __restrict__ q_canon, int nq,
+                                                              float* __restrict__ S, int64_t s_stride)
+{
+    constexpr int TQ = 32 * NQB;
+    constexpr int XV = (sizeof(T) == 4) ? 8 : 4;          // 16-byte loads per thread per chunk of the row tile
+    constexpr int QV = TQ * SM_KC / 4 / 256;              // float4 loads per thread per chunk of the query tile
+    static_assert(QV >= 1, "query tile too small for 256 threads");
+    __shared__ float xs[SM_ROWS * SM_LD];
+    __shared__ float qs[TQ * SM_LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int q0 = blockIdx.x * TQ;
+    const int r0 = blockIdx.y * SM_ROWS;
+    const T* base = rows + (row0 + r0) * (int64_t)d_pad;
+
+    uint4 xpre[XV];
+    float4 qpre[QV];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < XV; ++p) {
+            int r, c;                                      // row of the tile, first element of the 16-byte piece
+            if constexpr (sizeof(T) == 4) { r = (t >> 3) + 32 * p; c = (t & 7) * 4; }
+            else { r = (t >> 2) + 64 * p; c = (t & 3) * 8; }
+            xpre[p] = make_uint4(0, 0, 0, 0);
+            if (r0 + r < nrows) xpre[p] = *reinterpret_cast<const uint4*>(base + (int64_t)r * d_pad + k0 + c);
+        }
+#pragma unroll
+        for (int p = 0; p < QV; ++p) {
+            const int j = (t >> 3) + 32 * p, c = (t & 7) * 4;
+            qpre[p] = make_float4(0, 0, 0, 0);
+            if (q0 + j < nq) qpre[p] = *reinterpret_cast<const float4*>(q_canon + (int64_t)(q0 + j) * d_pad + k0 + c);
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int p = 0; p < XV; ++p) {
+            const uint4 v = xpre[p];
+            if constexpr (sizeof(T) == 4) {
+                float* dst = xs + ((t >> 3) + 32 * p) * SM_LD + (t & 7) * 4;
+                dst[0] = __builtin_bit_cast(float, v.x); dst[1] = __builtin_bit_cast(float, v.y);
+                dst[2] = __builtin_bit_cast(float, v.z); dst[3] = __builtin_bit_cast(float, v.w);
+            } else {
+                float* dst = xs + ((t >> 2) + 64 * p) * SM_LD + (t & 3) * 8;
+                dst[0] = __builtin_bit_cast(float, v.x << 16); dst[1] = __builtin_bit_cast(float, v.x & 0xFFFF0000u);
+                dst[2] = __builtin_bit_cast(float, v.y << 16); dst[3] = __builtin_bit_cast(float, v.y & 0xFFFF0000u);
+                dst[4] = __builtin_bit_cast(float, v.z << 16); dst[5] = __builtin_bit_cast(float, v.z & 0xFFFF0000u);
+                dst[6] = __builtin_bit_cast(float, v.w << 16); dst[7] = __builtin_bit_cast(float, v.w & 0xFFFF0000u);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < QV; ++p) {
+            float* dst = qs + ((t >> 3) + 32 * p) * SM_LD + (t & 7) * 4;
+            dst[0] = qpre[p].x; dst[1] = qpre[p].y; dst[2] = qpre[p].z; dst[3] = qpre[p].w;
+        }
+    };
+
+    f32x16 acc[NQB][2];
+#pragma unroll
+    for (int a = 0; a < NQB; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;      // the chain starts from +0.0f
+
+    const int l31 = lane & 31, h = lane >> 5;
+    const float* xa = xs + (64 * wave + l31) * SM_LD + h;          // + 32 rb rows, + 2 t
+    const float* qa = qs + l31 * SM_LD + h;                        // + 32 qb rows, + 2 t
+    fetch(0);
+    for (int k0 = 0; k0 < d_pad; k0 += SM_KC) {
+        park();
+        __syncthreads();
+        if (k0 + SM_KC < d_pad) fetch(k0 + SM_KC);
+#pragma unroll 4
+        for (int tp = 0; tp < SM_KC / 2; ++tp) {
+            float bx[2], aq[NQB];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bx[b] = xa[32 * b * SM_LD + 2 * tp];
+#pragma unroll
+            for (int a = 0; a < NQB; ++a) aq[a] = qa[32 * a * SM_LD + 2 * tp];
+#pragma unroll
+            for (int a = 0; a < NQB; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[a], bx[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D[i = query][j = row]: lane column = row (l & 31), register g -> query (g & 3) + 8 (g >> 2) + 4 h
+#pragma unroll
+    for (int a = 0; a < NQB; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int r = r0 + 64 * wave + 32 * b + l31;
+            if (r < nrows) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int q = q0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    if (q < nq) S[(int64_t)q * s_stride + r] = acc[a][b][g];
+                }
+            }
+        }
+}
+
+template <typename T>
+static void launch_scan_dense_mfma(hipStream_t st, const T* rows, int64_t row0, int nrows, int d_pad, const float* q_canon,
+                                   int nq, float* S, int64_t s_stride)
+{
+    const unsigned gy = (unsigned)((nrows + SM_ROWS - 1) / SM_ROWS);
+    if (nq <= 32) scan_dense_mfma_kernel<T, 1><<<dim3(1, gy), 256, 0, st>>>(rows, row0, nrows, d_pad, q_canon, nq, S, s_stride);
+    else scan_dense_mfma_kernel<T, 2><<<dim3((unsigned)((nq + 63) / 64), gy), 256, 0, st>>>(rows, row0, nrows, d_pad, q_canon, nq, S, s_stride);
+}
+
 int mi_launch_scan_dense(hipStream_t st, const void* rows, int dtype, int64_t row0, int nrows, int d_pad,
                          const float* q_canon, int nq, float* S, int64_t s_stride)
 {
@@ -192,6 +323,15 @@ int mi_launch_scan_dense(hipStream_t st, const void* rows, int dtype, int64_t ro
     }
     dim3 grid((nq + SD_Q - 1) / SD_Q, (nrows + SD_ROWS - 1) / SD_ROWS);
     if (grid.y > 65535) { mi_set_error("scan_dense: segment too long"); return MI_ERR_INTERNAL; }
+    // more than one 16-query group: the fp32 MFMA kernel (MI_EXACT_MFMA=0 keeps the VALU kernel, for A/B runs and
+    // so that the tests can hold both to the oracle)
+    static const bool mfma_off = getenv("MI_EXACT_MFMA") && atoi(getenv("MI_EXACT_MFMA")) == 0;
+    if (nq > SD_Q && !mfma_off) {
+        if (dtype == MI_DTYPE_F32) launch_scan_dense_mfma<float>(st, (const float*)rows, row0, nrows, d_pad, q_canon, nq, S, s_stride);
+        else launch_scan_dense_mfma<uint16_t>(st, (const uint16_t*)rows, row0, nrows, d_pad, q_canon, nq, S, s_stride);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    }
     if (dtype == MI_DTYPE_F32)
         scan_dense_kernel<float><<<grid, 256, 0, st>>>((const float*)rows, row0, nrows, d_pad, q_canon, nq, S, s_stride);
     else

@@ -1010,12 +1010,16 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
         if (v >= 8 && v <= spg_max * gmax && n / v >= MF_TILE_R) ns = v;
     }
     const int ngroups = (ns + spg_max - 1) / spg_max;
-    plan->pd = (nqt <= 2) ? 3 : 2;
+    // Up to 128 queries (four active waves, one per SIMD) the scan is HBM-bound: deep prefetch, 32x32x16.  Beyond,
+    // both waves of every SIMD carry MFMAs and the variant with the mid-unit barrier wins, also where the slice is
+    // still read by one or two query tiles only (100M x 384, one device: Q = 256 20.7 -> 18.9 ms, Q = 512
+    // 36.5 -> 33.3 ms, Q = 128 13.9 vs 13.85 ms; profiles/r02_midq_variants.jsonl)
+    plan->pd = (nq <= 128) ? 3 : 2;
+    if (const char* e = getenv("MI_MFMA_PD")) { const int v = atoi(e); if (v == 2 || v == 3) plan->pd = v; }
     // MFMA shape: 16x16x32 in the MFMA-bound variant (+8.6 % at 100M x 384 on one device: same
     // cycles, higher sustained clock); MI_MFMA_M16=0 selects 32x32x16 for A/B runs
     plan->m16 = (plan->pd == 2) ? 1 : 0;
     if (const char* e = getenv("MI_MFMA_M16")) plan->m16 = (atoi(e) != 0 && plan->pd == 2) ? 1 : 0;
-    if (const char* e = getenv("MI_MFMA_PD")) { const int v = atoi(e); if (v == 2 || v == 3) plan->pd = v; }
     plan->kprime = kp;
     plan->cap = cap;
     plan->nslices = ns;

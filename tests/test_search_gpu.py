@@ -44,6 +44,59 @@ def test_exact_path_matches_oracle(oracle_mod, metric, dtype, n, d, nq, k):
     _check(oracle_mod, _unit(rng, n, d), _unit(rng, nq, d), k, metric, dtype, mode=MODE_EXACT)
 
 
+@pytest.mark.parametrize("metric,dtype", [("ip", "f32"), ("l2", "bf16")])
+def test_exact_path_on_the_fp32_matrix_pipe(oracle_mod, metric, dtype):
+    """More than 16 queries: scan_dense runs on v_mfma_f32_32x32x2_f32 (search_exact.hip), whose accumulation is the
+    k-ordered fmaf chain itself.  300 queries (five 64-query tiles, the last partial) over 70,001 rows (a partial
+    row tile), rows with NaN, +-0, denormal-scale and huge values, duplicates: bit-exact ids and score bits."""
+    from rag_amd.index import MODE_EXACT
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 70_001, 384, 300, 10
+    X = _unit(rng, n, d)
+    X[11] = 0.0
+    X[12] = -0.0
+    X[13] *= 1e-38                                   # products and sums in the denormal range
+    X[14] *= 1e18
+    X[15, 7] = np.nan
+    X[5000:5040] = X[3]
+    Q = _unit(rng, nq, d)
+    Q[0] = X[3]
+    Q[1] *= 1e-7
+    Q[2] = -X[14] * 1e-18
+    _check(oracle_mod, X, Q, k, metric, dtype, mode=MODE_EXACT)
+    # 17 .. 32 queries take the one-block variant
+    _check(oracle_mod, X[:9000], Q[:29], 33, metric, dtype, mode=MODE_EXACT)
+
+
+_VALU_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import oracle
+from rag_amd.index import FlatIndex, MODE_EXACT
+rng = np.random.default_rng(6)
+X = rng.standard_normal((30000, 200)).astype(np.float32); Q = rng.standard_normal((70, 200)).astype(np.float32)
+for dtype, odt in (("f32", oracle.DTYPE_F32), ("bf16", oracle.DTYPE_BF16)):
+    idx = FlatIndex(200, metric="l2", dtype=dtype); idx.set_mode(MODE_EXACT); idx.add(X)
+    D, I = idx.search(Q, 10)
+    Do, Io = oracle.search(X, Q, 10, metric=oracle.METRIC_L2, dtype=odt)
+    assert np.array_equal(I, Io) and np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+print("OK")
+"""
+
+
+def test_valu_scan_stays_covered_in_a_child_process():
+    """MI_EXACT_MFMA=0 keeps the fp32 VALU scan for more than 16 queries (the kernel the MFMA one replaced; still the
+    path for 5 .. 16 queries): read once per process, so a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e["MI_EXACT_MFMA"] = "0"
+    out = subprocess.run([sys.executable, "-c", _VALU_CHILD % root], env=e, capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
 @pytest.mark.parametrize("metric", ["ip", "l2"])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("n,d,nq,k", [(2000, 384, 1, 5), (20000, 384, 1, 5), (50000, 100, 3, 100), (200000, 384, 2, 5),
