@@ -888,6 +888,14 @@ __global__ __launch_bounds__(256) void cvt_pack_w1_kernel(const float* __restric
     }
 }
 
+#ifdef FF_TRACE
+// Debug build only (tools/build_trace.sh): cycle stamps of the phases of eight workgroups of ffn_ln_kernel.
+__device__ uint32_t ff_trace_buf[8][8][16];
+#define FF_STAMP(k) do { if (ff_slot >= 0 && lane == 0) ff_trace_buf[ff_slot][wave][k] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FF_STAMP(k) do { } while (0)
+#endif
+
 // FRONT: the attention output projection + residual + LayerNorm (what gemm_ln_kernel does for K = 384) runs first, on the
 // same 128 rows: h is then the layer's input (the residual of that LayerNorm), its result never goes to HBM -- it is
 // parked in LDS, becomes the h fragments of step 1 and the residual of the final LayerNorm.
@@ -908,6 +916,11 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
     const int m0 = (int)(gridDim.x - 1 - blockIdx.x) * 128;
     const int nkt = I / 32;                                        // >= 4
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+#ifdef FF_TRACE
+    const int ff_slot = (blockIdx.x % 64 == 0 && blockIdx.x / 64 < 8) ? (int)(blockIdx.x / 64) : -1;
+    if (ff_slot >= 0 && lane == 0) ff_trace_buf[ff_slot][wave][15] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
+    FF_STAMP(0);
 
     // b1 -> LDS
     for (int i = threadIdx.x; i < I / 4; i += 512)
@@ -919,7 +932,9 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
         static_assert(FF_B1_OFF >= 4 * LN_STAGE + 3 * LN_N * 4, "b1 sits behind the front phase's ring and parameters");
         uint2 rres[2][12];
         rowgemm384_mainloop(lds, ctx, Wo_p, bo, h, gamma1, beta1, M, LN_N, 1, m0, lane, wave, acc, rres);
+        FF_STAMP(1);
         ln_rows_epilogue<false>(lds, reinterpret_cast<const float*>(lds + 4 * LN_STAGE), acc, rres, nullptr, m0, M, eps, wm, wn, l15, g4);
+        FF_STAMP(2);
 #pragma unroll
         for (int sk = 0; sk < 12; ++sk)
             hq[sk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + 4096 + (16 * wave + l15) * LN_TS + (32 * sk + 8 * g4) * 2));
@@ -935,6 +950,7 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
         for (int sk = 0; sk < 12; ++sk) asm volatile("" :: "v"(hq[sk]));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FF_STAMP(3);
 
     // ---- LDS-DMA: per block 24 pieces of 1 KB; wave w issues pieces 3w..3w+2 of each
     const char* w2src[3];
@@ -1021,6 +1037,7 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
     issue_w1(0); issue_w1(1); issue_w1(2); issue_w2(0); issue_w2(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    FF_STAMP(4);
     {
         float4 bb[2];
 #pragma unroll
@@ -1034,6 +1051,7 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                  // everyone has left W1(0): its buffer takes W1(3)
     if (3 < nkt) issue_w1(3);
+    FF_STAMP(5);
 
     for (int kt = 0; kt < nkt; ++kt) {
         // behind this barrier: W2(kt) and W1(kt + 2) have landed for everyone (requested two stages ago),
@@ -1096,6 +1114,7 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                               // the rings become the epilogue's scratch
+    FF_STAMP(6);
 
     float* const prm = reinterpret_cast<float*>(lds + 4096 + 128 * LN_TS);
     if (threadIdx.x < 3 * LN_N / 4) {
@@ -1115,7 +1134,12 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
 #pragma unroll
         for (int nb = 0; nb < 12; ++nb)
             rres[mb][nb] = *reinterpret_cast<const uint2*>(park + (32 * wm + 16 * mb + l15) * LN_TS + (192 * wn + 16 * nb + 4 * g4) * 2);
+    FF_STAMP(7);
     ln_rows_epilogue(lds, prm, acc, rres, out, m0, M, eps, wm, wn, l15, g4);   // (its park writes come two barriers later)
+    FF_STAMP(8);
+#ifdef FF_TRACE
+    if (ff_slot >= 0 && lane == 0) ff_trace_buf[ff_slot][wave][14] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------- attention (head size 32)
@@ -2095,3 +2119,10 @@ extern "C" int mi_encoder_last_time(const mi_encoder* enc, float* out_ms)
     MI_HIP(hipEventElapsedTime(out_ms, e->ev0, e->ev1));
     return MI_OK;
 }
+
+#ifdef FF_TRACE
+extern "C" int mi_debug_read_ff_trace(void* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_trace_buf), sizeof(ff_trace_buf));
+}
+#endif

@@ -62,7 +62,13 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 #define MF_MIN_ROWS 32768
 
 __host__ __device__ constexpr int mf_cap(int kp) { return 2 * kp + 32; }
-__host__ __device__ constexpr int mf_waves(int nkb) { return nkb <= 3 ? 8 : 4; }   // 32 queries per wave
+// Waves per workgroup and 16-query blocks per wave.  d <= 384: 8 waves x 32 queries (96 VGPRs of query fragments).
+// d = 768: the 32x32x16 (HBM-bound) variant keeps 4 waves x 32 queries, one per SIMD with the 512-register budget;
+// the 16x16x32 (MFMA-bound) variant runs 8 waves x 16 queries, two per SIMD: a wave alone on its SIMD has nothing
+// to hide its barriers, DMA issue and LDS latency behind (0.84 PFLOP/s at 5M x 768 x 10k in round 1).
+__host__ __device__ constexpr int mf_waves(int nkb, bool m16) { return (nkb <= 3 || m16) ? 8 : 4; }
+__host__ __device__ constexpr int mf_qb(int nkb, bool m16) { return (nkb > 3 && m16) ? 1 : 2; }
+__host__ __device__ constexpr int mf_qtile(int nkb, bool m16) { return 16 * mf_qb(nkb, m16) * mf_waves(nkb, m16); }
 
 // Four A fragments (rows 32 m + col, m = 0..3) of one k-step; completion is the caller's
 // s_waitcnt lgkmcnt (hipcc does not count inline-asm LDS reads).
@@ -142,12 +148,15 @@ __device__ __forceinline__ int mf_trace_slot(int b) { return b == 3 ? 0 : b == 3
 #endif
 
 template <int NKB, int KP, bool L2, int PD, bool M16>
-__global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
+__global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
     const uint16_t* __restrict__ rows, const float* __restrict__ xx, int64_t n, int pitch_bytes,
     const uint16_t* __restrict__ q_bf16, int nq, int nq_pad, int nqt, int64_t slice_rows,
     uint64_t* __restrict__ lists, int32_t* __restrict__ cnts, float* __restrict__ thrs, uint32_t* __restrict__ gthr)
 {
-    constexpr int WAVES = mf_waves(NKB);
+    constexpr int WAVES = mf_waves(NKB, M16);
+    constexpr int QB = mf_qb(NKB, M16);               // 16-query blocks per wave
+    constexpr int QW = 16 * QB;                       // queries per wave
+    static_assert(M16 || QB == 2, "the 32x32x16 variant holds 32 queries per wave");
     constexpr int PPW = 32 / WAVES;                   // 1-KiB LDS-DMA pieces per wave per unit
     constexpr int CAP = mf_cap(KP);
     constexpr int EPL = (CAP + 63) / 64;
@@ -177,27 +186,29 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     const int qt = j % nqt;
 
     const int d_pad = pitch_bytes >> 1;
-    const int64_t qglob = (int64_t)qt * (32 * WAVES) + wave * 32 + col;   // this lane's query
-    const bool active = (int64_t)qt * (32 * WAVES) + wave * 32 < nq;      // wave-uniform
+    const int64_t qglob = (int64_t)qt * (QW * WAVES) + wave * QW + col;   // this lane's query (32x32x16 variant)
+    const bool active = (int64_t)qt * (QW * WAVES) + wave * QW < nq;      // wave-uniform
 
-    const int64_t qbase = (int64_t)qt * (32 * WAVES) + wave * 32;         // first query of this wave
+    const int64_t qbase = (int64_t)qt * (QW * WAVES) + wave * QW;         // first query of this wave
     const int l15 = lane & 15, g4 = lane >> 4;                            // 16x16x32 lane coordinates
 
     // ---- B fragments.  32x32x16: lane (col, h) holds query qglob, dims [16 s + 8 h, +8).
     // 16x16x32: lane (l15, g4) holds queries qbase + 16 cb + l15 (cb = 0, 1), dims [32 s + 8 g4, +8).
     bf16x8 bq[M16 ? 1 : KS];
-    bf16x8 bq16[M16 ? KS / 2 : 1][2];
+    bf16x8 bq16[M16 ? KS / 2 : 1][QB];
     if (active) {
         if constexpr (M16) {
 #pragma unroll
             for (int s = 0; s < KS / 2; ++s)
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
+                for (int cb = 0; cb < QB; ++cb) {
                     const uint4 v = *reinterpret_cast<const uint4*>(q_bf16 + (qbase + 16 * cb + l15) * d_pad + 32 * s + 8 * g4);
                     bq16[s][cb] = __builtin_bit_cast(bf16x8, v);
                 }
 #pragma unroll
-            for (int s = 0; s < KS / 2; ++s) asm volatile("" :: "v"(bq16[s][0]), "v"(bq16[s][1]));
+            for (int s = 0; s < KS / 2; ++s)
+#pragma unroll
+                for (int cb = 0; cb < QB; ++cb) asm volatile("" :: "v"(bq16[s][cb]));
         } else {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -290,12 +301,12 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     float thr = (qglob < nq) ? -__builtin_inff() : __builtin_inff();
     int cnt = 0;
     uint64_t* const list = lists + ((int64_t)slice * nq_pad + qglob) * CAP;
-    float thr2[2] = {(qbase + l15 < nq) ? -__builtin_inff() : __builtin_inff(),       // 16x16x32: the lane's two queries
-                     (qbase + 16 + l15 < nq) ? -__builtin_inff() : __builtin_inff()};
+    float thr2[2] = {(qbase + l15 < nq) ? -__builtin_inff() : __builtin_inff(),       // 16x16x32: the lane's QB queries
+                     (QB > 1 && qbase + 16 + l15 < nq) ? -__builtin_inff() : __builtin_inff()};
     int cnt2[2] = {0, 0};
 
     f32x16 acc[M16 ? 1 : 4];
-    f32x4 acc16[M16 ? 8 : 1][2];                                  // [16-row block][16-query block]
+    f32x4 acc16[M16 ? 8 : 1][QB];                                 // [16-row block][16-query block]
     auto init_acc = [&](int tile) __attribute__((always_inline)) {
         if constexpr (M16) {
             if constexpr (L2) {
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                 for (int rb = 0; rb < 8; ++rb) {
                     const float4 v = *reinterpret_cast<const float4*>(xl + 16 * rb + 4 * g4);
 #pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) {
+                    for (int cb = 0; cb < QB; ++cb) {
                         acc16[rb][cb][0] = -0.5f * v.x; acc16[rb][cb][1] = -0.5f * v.y;
                         acc16[rb][cb][2] = -0.5f * v.z; acc16[rb][cb][3] = -0.5f * v.w;
                     }
@@ -333,7 +344,10 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
     // 10 = unit u + 2 issued right behind the barrier of unit u.  Measured on one device (20M and
     // 100M rows, 10k queries): 25 is 2-3 % faster at d = 384, 10 is 2 % faster at d = 768 and moves
     // half the bytes over the fabric (the workgroups of a slice stay closer in L2); 15 and 20 lose.
-    constexpr int MF_LEAD = (NKB >= 6) ? 10 : 25;
+#ifndef MF_LEAD_768
+#define MF_LEAD_768 10
+#endif
+    constexpr int MF_LEAD = (NKB >= 6) ? MF_LEAD_768 : 25;
     constexpr int MF_PRO = M16 ? (MF_LEAD >= 20 ? 3 : 2) : MF_PD;
 #pragma unroll
     for (int u0 = 0; u0 < MF_PRO; ++u0)
@@ -400,6 +414,37 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                              "ds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %4 offset:12288"
                              : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]) : "v"(ad));
         };
+        if constexpr (QB == 1) {
+            // 16 queries per wave: a fragment feeds ONE MFMA, so four reads cover only 64 cycles of MFMA -- less than the
+            // LDS round trip.  Read a whole k-step (eight row blocks) ahead instead: 128 cycles of cover.
+            bf16x8 b[2][8];
+            auto rd8 = [&](bf16x8 (&f)[8], int ks) __attribute__((always_inline)) {
+                rd(reinterpret_cast<bf16x8 (&)[4]>(f[0]), 2 * ks);
+                rd(reinterpret_cast<bf16x8 (&)[4]>(f[4]), 2 * ks + 1);
+            };
+            rd8(b[0], 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < 3) {
+                    rd8(b[(t + 1) & 1], t + 1);
+                    asm volatile("s_waitcnt lgkmcnt(8)"
+                                 : "+v"(b[t & 1][0]), "+v"(b[t & 1][1]), "+v"(b[t & 1][2]), "+v"(b[t & 1][3]),
+                                   "+v"(b[t & 1][4]), "+v"(b[t & 1][5]), "+v"(b[t & 1][6]), "+v"(b[t & 1][7]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(b[t & 1][0]), "+v"(b[t & 1][1]), "+v"(b[t & 1][2]), "+v"(b[t & 1][3]),
+                                   "+v"(b[t & 1][4]), "+v"(b[t & 1][5]), "+v"(b[t & 1][6]), "+v"(b[t & 1][7]));
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (!L2 && KB == 0 && t == 0)      // first touch in the tile: C = 0 (no zeroing pass)
+                        acc16[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[t & 1][r], bq16[KB * 4 + t][0], f32x4{}, 0, 0, 0);
+                    else
+                        acc16[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[t & 1][r], bq16[KB * 4 + t][0], acc16[r][0], 0, 0, 0);
+                }
+                if (t == 1) mid();
+            }
+        } else {
         rd(a[0], 0);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -414,7 +459,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
+                for (int cb = 0; cb < QB; ++cb) {
                     if (!L2 && KB == 0 && t < 2)       // first touch in the tile: C = 0 (no zeroing pass)
                         acc16[4 * (t & 1) + r][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             a[t & 1][r], bq16[KB * 4 + (t >> 1)][cb], f32x4{}, 0, 0, 0);
@@ -423,6 +468,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                             a[t & 1][r], bq16[KB * 4 + (t >> 1)][cb], acc16[4 * (t & 1) + r][cb], 0, 0, 0);
                 }
             if (t == 3) mid();
+        }
         }
     };
 
@@ -482,7 +528,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
         const char* gslot = lds + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256;
         if constexpr (M16) {
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
+            for (int cb = 0; cb < QB; ++cb) {
                 const uint32_t gw = *reinterpret_cast<const uint32_t*>(gslot + (16 * cb + l15) * 4);
                 if (gw != 0) thr2[cb] = __builtin_fmaxf(thr2[cb], mi_unord_f32(gw));
             }
@@ -501,7 +547,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
             {
                 float m[2];
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
+                for (int cb = 0; cb < QB; ++cb) {
                     float m4[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) m4[i] = __builtin_fmaxf(acc16[0][cb][i], acc16[1][cb][i]);
@@ -511,11 +557,13 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
                         for (int i = 0; i < 4; ++i) m4[i] = __builtin_fmaxf(m4[i], acc16[rb][cb][i]);
                     m[cb] = __builtin_fmaxf(__builtin_fmaxf(m4[0], m4[1]), __builtin_fmaxf(m4[2], m4[3]));
                 }
-                if (__builtin_amdgcn_ballot_w64((m[0] > thr2[0]) || (m[1] > thr2[1])) == 0) return;
+                bool any = m[0] > thr2[0];
+                if constexpr (QB > 1) any = any || (m[1] > thr2[1]);
+                if (__builtin_amdgcn_ballot_w64(any) == 0) return;
             }
             const uint32_t rowbase = (uint32_t)(row_begin + (int64_t)tile * MF_TILE_R) + 4u * (uint32_t)g4;
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
+            for (int cb = 0; cb < QB; ++cb) {
                 uint64_t* const list16 = lists + ((int64_t)slice * nq_pad + qbase + 16 * cb + l15) * CAP;
 #pragma unroll
                 for (int rp = 0; rp < 4; ++rp) {                  // 32 rows at a time, as the list capacity assumes
@@ -724,7 +772,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB)) void mfma_scan_kernel(
         if (threadIdx.x == 0 && nqt <= 64) __hip_atomic_store(prog + qt, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (g4 == 0) {
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
+            for (int cb = 0; cb < QB; ++cb) {
                 cnts[(int64_t)slice * nq_pad + qbase + 16 * cb + l15] = cnt2[cb];
                 thrs[(int64_t)slice * nq_pad + qbase + 16 * cb + l15] = thr2[cb];
             }
@@ -990,7 +1038,8 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
 {
     const int nkb = pick_nkb(d_pad), kp = pick_kp(k);
     if (!nkb || !kp || n < MF_MIN_ROWS || n >= ((int64_t)1 << 32) || k > MF_SORT_MAX / 2) return MI_ERR_UNSUPPORTED;
-    const int qtile = 32 * mf_waves(nkb);
+    const int qtile = mf_qtile(nkb, false);                       // the same for both kernel variants of a dimension
+    static_assert(mf_qtile(6, false) == mf_qtile(6, true) && mf_qtile(3, false) == mf_qtile(3, true) && mf_qtile(1, false) == mf_qtile(1, true), "query tile");
     const int cap = mf_cap(kp);
     const int64_t nqt = (nq + qtile - 1) / qtile;
     const int spg_max = (MF_PH2_MAX / cap) / 8 * 8;               // slices whose lists fit one finish block
@@ -1037,10 +1086,10 @@ template <int NKB, int KP, bool L2, int PD, bool M16>
 static void launch_scan(hipStream_t st, const mi_mfma_plan* p, const uint16_t* rows, const float* xx, int64_t n,
                         int d_pad, const uint16_t* q_bf16, int nq, uint64_t* lists, int32_t* cnts, float* thrs, uint32_t* gthr)
 {
-    const int qtile = 32 * mf_waves(NKB);
+    const int qtile = mf_qtile(NKB, M16);
     const int nqt = p->nq_pad / qtile;
     const unsigned grid = (unsigned)(nqt * p->nslices);
-    mfma_scan_kernel<NKB, KP, L2, PD, M16><<<grid, 64 * mf_waves(NKB), 0, st>>>(rows, xx, n, d_pad * 2, q_bf16, nq, p->nq_pad, nqt,
+    mfma_scan_kernel<NKB, KP, L2, PD, M16><<<grid, 64 * mf_waves(NKB, M16), 0, st>>>(rows, xx, n, d_pad * 2, q_bf16, nq, p->nq_pad, nqt,
                                                                        p->slice_rows, lists, cnts, thrs, gthr);
 }
 

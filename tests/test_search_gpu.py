@@ -161,7 +161,8 @@ def test_mfma_path_all_metrics_and_dtypes(oracle_mod, metric, dtype, n, d, nq, k
     assert st["fast"] + st["exact"] == nq
     # a bf16 index certifies nearly always; the rounded shadow of an F32 index widens the bound
     # (2^-8 |q||x|), which at this small n / few slices sends more queries to the exact path
-    assert st["fast"] >= nq * (0.8 if dtype == "bf16" else 0.0), st
+    # measured in round 2: every case here certifies all of its queries, fp32 indexes included
+    assert st["fast"] >= nq * (0.8 if dtype == "bf16" else 0.7), st
     print(f"certified {st['fast']}/{nq} ({metric}, {dtype}, n={n})")
 
 
@@ -332,6 +333,9 @@ def test_answer_is_invariant_under_row_permutation_and_batching(oracle_mod):
     ("ip", "bf16", 90000, 128, 1000, 5),       # one k-block per row
     ("ip", "bf16", 50000, 768, 520, 10),       # six k-blocks, four waves per workgroup (128-query tiles)
     ("ip", "bf16", 60000, 384, 800, 100),      # K' = 128 lists
+    ("ip", "bf16", 50000, 768, 520, 100),      # BASELINE config 5's instance: 768-d, K' = 128, eight waves x 16 queries
+    ("l2", "bf16", 50000, 768, 520, 100),      # the same with the accumulators started at -xx / 2
+    ("ip", "f32", 50000, 768, 300, 100),       # fp32 768-d index: bf16 shadow + fp32 re-score
 ])
 def test_mfma_bound_variant_matches_oracle(oracle_mod, metric, dtype, n, d, nq, k):
     """More than two query tiles per slice: the plan takes the MFMA-bound kernel variant (16x16x32 MFMA, mid-unit
@@ -378,6 +382,42 @@ def test_plan_overrides_do_not_change_the_answer(env):
     e.update(env)
     out = subprocess.run([sys.executable, "-c", _PLAN_CHILD % root], env=e, capture_output=True, text=True, timeout=170)
     assert out.returncode == 0 and "OK" in out.stdout, (env, out.stdout[-500:], out.stderr[-2000:])
+
+
+def test_config5_size_properties(oracle_mod):
+    """BASELINE config 5 at its full single-GPU size (50M x 768 bf16 = 76.8 GB, top-100, 10k queries), where the oracle
+    cannot follow: best-first order, reported scores equal to the canonical chain of rows regenerated on the CPU,
+    planted rows first, a query's answer independent of the batch (and so of the kernel variant) it travelled in,
+    no exact-path fallback."""
+    import torch
+    from rag_amd.index import FlatIndex, MODE_FAST
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100e9:
+        pytest.skip("needs ~90 GB of HBM")
+    n, d, nq, k = 50_000_000, 768, 10_000, 100
+    idx = FlatIndex(d, metric="ip", dtype="bf16")
+    idx.set_mode(MODE_FAST)
+    idx.add_synthetic(n, seed=0)
+    Q = oracle_mod.synth_rows(1, 0, nq, d)
+    planted = [0, 123_456, 25_000_000, n - 1]
+    for j, r in enumerate(planted):
+        Q[j] = oracle_mod.synth_rows(0, r, 1, d)[0]
+    D, I = idx.search(Q, k)
+    st = idx.stats()
+    assert st["fast"] == nq and st["exact"] == 0, st
+    assert np.all(D[:, :-1] >= D[:, 1:]) and I.min() >= 0 and I.max() < n
+    assert all(len(set(row)) == k for row in I[::997])
+    for j, r in enumerate(planted):
+        assert I[j, 0] == r, (j, r, I[j, :3])
+    for qi in (0, 3, 17, 5000, nq - 1):
+        for j in (0, 49, k - 1):
+            x = oracle_mod.synth_rows(0, int(I[qi, j]), 1, d)[0]
+            want = np.float32(oracle_mod.score_pair(Q[qi], x, metric=oracle_mod.METRIC_IP, dtype=oracle_mod.DTYPE_BF16))
+            assert want.view(np.uint32) == D[qi, j].view(np.uint32), (qi, j)
+    sub = [1, 4, 99, 2500, 7777, 9000, nq - 1]
+    D7, I7 = idx.search(Q[sub], k)
+    assert np.array_equal(I7, I[sub]) and np.array_equal(D7.view(np.uint32), D[sub].view(np.uint32))
+    print(f"config 5: scan {idx.last_scan_time()}")
 
 
 def test_bench_size_properties(oracle_mod):
