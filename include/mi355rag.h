@@ -120,6 +120,13 @@ int  mi_index_reset(mi_index* idx);
  * index) — faiss reconstruct_n; used by the parity tests. */
 int  mi_index_get_rows(mi_index* idx, int64_t row0, int64_t n, float* out_host);
 
+/* Shard files (the reference never persists, advanced_rag.py:435-437): rows in the index's
+ * own storage type -- fp32, or bf16 bit patterns as uint16 -- row pitch = dim elements, no widening on the way
+ * out; and the matching add from host rows of either type (src_dtype MI_DTYPE_F32 / MI_DTYPE_BF16). */
+int  mi_index_get_rows_raw(mi_index* idx, int64_t row0, int64_t n, void* out_host);
+int  mi_index_add_raw(mi_index* idx, int64_t n, const void* x_host, int src_dtype);
+int  mi_index_dtype(const mi_index* idx);
+
 /* Exact top-k.  index.search(np.array([v], float32), k) in the reference
  * (advanced_rag.py:296 -> similarity_search -> faiss IndexFlat::search).
  * q_host [nq][dim] fp32; out_scores [nq][k] fp32; out_ids [nq][k] int64 (-1 padded). */

@@ -61,6 +61,9 @@ SYMBOLS = {
     "mi_index_set_mode": (_i32, [_vp, _i32]),
     "mi_index_reset": (_i32, [_vp]),
     "mi_index_get_rows": (_i32, [_vp, _i64, _i64, _vp]),
+    "mi_index_get_rows_raw": (_i32, [_vp, _i64, _i64, _vp]),
+    "mi_index_add_raw": (_i32, [_vp, _i64, _vp, _i32]),
+    "mi_index_dtype": (_i32, [_vp]),
     "mi_index_search": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp]),
     "mi_index_search_dev": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     "mi_index_stats": (_i32, [_vp, ctypes.POINTER(ctypes.c_int64)]),

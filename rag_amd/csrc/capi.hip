@@ -264,6 +264,24 @@ extern "C" int mi_index_add_dev(mi_index* idx, int64_t n, const void* x_dev, int
     return add_dev_locked(idx, n, x_dev, src_dtype, mi_pick_stream(stream, idx->ctx->stream));
 }
 
+// Host rows of either dtype, staged through a device buffer in slabs (bounded extra memory for huge adds).
+static int add_host_locked(mi_index* idx, int64_t n, const void* x_host, int src_dtype)
+{
+    hipStream_t st = idx->ctx->stream;
+    const size_t esz = src_dtype == MI_DTYPE_F32 ? 4 : 2;
+    const size_t row_bytes = (size_t)idx->d * esz;
+    const int64_t slab = (int64_t)((256ull << 20) / row_bytes) > 0 ? (int64_t)((256ull << 20) / row_bytes) : 1;
+    const int64_t first = n < slab ? n : slab;
+    MI_TRY(idx->stage.ensure((size_t)first * row_bytes));
+    for (int64_t off = 0; off < n; off += slab) {
+        const int64_t m = (n - off < slab) ? n - off : slab;
+        MI_HIP(hipMemcpyAsync(idx->stage.p, static_cast<const char*>(x_host) + (size_t)off * row_bytes, (size_t)m * row_bytes, hipMemcpyHostToDevice, st));
+        MI_TRY(add_dev_locked(idx, m, idx->stage.p, src_dtype, st));
+        MI_HIP(hipStreamSynchronize(st));          // the slab is reused; the caller's buffer is free on return
+    }
+    return MI_OK;
+}
+
 extern "C" int mi_index_add(mi_index* idx, int64_t n, const float* x_host)
 {
     MI_REQUIRE(idx && n >= 0 && (x_host || n == 0), "mi_index_add: bad argument");
@@ -271,18 +289,17 @@ extern "C" int mi_index_add(mi_index* idx, int64_t n, const float* x_host)
     // one lock for the whole call: the rows of two concurrent adds never interleave
     std::lock_guard<std::mutex> lk(idx->mu);
     DeviceGuard g(idx->ctx->device);
-    hipStream_t st = idx->ctx->stream;
-    // stage through a device buffer in slabs (bounded extra memory for huge adds)
-    const int64_t slab = (int64_t)((256ull << 20) / ((size_t)idx->d * 4)) > 0 ? (int64_t)((256ull << 20) / ((size_t)idx->d * 4)) : 1;
-    const int64_t first = n < slab ? n : slab;
-    MI_TRY(idx->stage.ensure((size_t)first * idx->d * 4));
-    for (int64_t off = 0; off < n; off += slab) {
-        const int64_t m = (n - off < slab) ? n - off : slab;
-        MI_HIP(hipMemcpyAsync(idx->stage.p, x_host + off * idx->d, (size_t)m * idx->d * 4, hipMemcpyHostToDevice, st));
-        MI_TRY(add_dev_locked(idx, m, idx->stage.p, MI_DTYPE_F32, st));
-        MI_HIP(hipStreamSynchronize(st));          // the slab is reused; the caller's buffer is free on return
-    }
-    return MI_OK;
+    return add_host_locked(idx, n, x_host, MI_DTYPE_F32);
+}
+
+extern "C" int mi_index_add_raw(mi_index* idx, int64_t n, const void* x_host, int src_dtype)
+{
+    MI_REQUIRE(idx && n >= 0 && (x_host || n == 0), "mi_index_add_raw: bad argument");
+    MI_REQUIRE(src_dtype == MI_DTYPE_F32 || src_dtype == MI_DTYPE_BF16, "mi_index_add_raw: unknown src dtype");
+    if (n == 0) return MI_OK;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    DeviceGuard g(idx->ctx->device);
+    return add_host_locked(idx, n, x_host, src_dtype);
 }
 
 extern "C" int mi_index_add_synthetic(mi_index* idx, int64_t n, uint64_t seed, int normalize)
@@ -354,6 +371,27 @@ extern "C" int mi_index_get_rows(mi_index* idx, int64_t row0, int64_t n, float* 
     }
     return MI_OK;
 }
+
+// Rows [row0, row0 + n) in the index's own storage type (fp32, or bf16 bit patterns), row pitch = dim elements: what a
+// shard file holds (no widening to fp32 on the way out).
+extern "C" int mi_index_get_rows_raw(mi_index* idx, int64_t row0, int64_t n, void* out_host)
+{
+    MI_REQUIRE(idx && out_host && row0 >= 0 && n >= 0, "mi_index_get_rows_raw: bad argument");
+    std::lock_guard<std::mutex> lk(idx->mu);
+    MI_REQUIRE(row0 + n <= idx->n, "mi_index_get_rows_raw: range [%lld,%lld) outside [0,%lld)",
+               (long long)row0, (long long)(row0 + n), (long long)idx->n);
+    if (n == 0) return MI_OK;
+    DeviceGuard g(idx->ctx->device);
+    hipStream_t st = idx->ctx->stream;
+    MI_HIP(hipStreamWaitEvent(st, idx->ev_data, 0));
+    const size_t esz = idx->elem();
+    MI_HIP(hipMemcpy2DAsync(out_host, (size_t)idx->d * esz, row_ptr(idx, row0), (size_t)idx->d_pad * esz, (size_t)idx->d * esz, (size_t)n,
+                            hipMemcpyDeviceToHost, st));
+    MI_HIP(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+extern "C" int mi_index_dtype(const mi_index* idx) { return idx ? idx->dtype : -1; }
 
 extern "C" int mi_index_stats(const mi_index* idx, int64_t out[4])
 {

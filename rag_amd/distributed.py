@@ -123,6 +123,62 @@ class ShardedFlatIndex:
         return D.numpy(), I.numpy()
 
 
+    # ---- persistence: one row-major shard file per rank
+    def save_local(self, folder_path: str, index_name: str = "index") -> None:
+        """Rank r writes `<name>.shard<r>.rows.npy` -- its rows in the storage type (bf16 bit patterns as uint16, or
+        fp32), row-major, streamed in slabs -- and `<name>.shard<r>.json` (its global row range); rank 0 adds
+        `<name>.shards.json`.  No collective besides a closing barrier; nothing is unpickled on load."""
+        import json
+        import os
+        os.makedirs(folder_path, exist_ok=True)
+        n = self.local.ntotal
+        lo = int(getattr(self.local, "id_base", None) if getattr(self.local, "id_base", None) is not None
+                 else shard_range(self.n_total, self.world, self.rank)[0])
+        npdt = np.uint16 if self.dtype in ("bf16", "bfloat16") else np.float32
+        path = os.path.join(folder_path, f"{index_name}.shard{self.rank:03d}.rows.npy")
+        mm = np.lib.format.open_memmap(path, mode="w+", dtype=npdt, shape=(n, self.d))
+        slab = max(1, (256 << 20) // (self.d * 4))
+        for r0 in range(0, n, slab):
+            m = min(slab, n - r0)
+            mm[r0:r0 + m] = self.local.reconstruct_raw(r0, m)
+        mm.flush()
+        del mm
+        with open(os.path.join(folder_path, f"{index_name}.shard{self.rank:03d}.json"), "w") as f:
+            json.dump({"row0": lo, "rows": n}, f)
+        if self.rank == 0:
+            with open(os.path.join(folder_path, f"{index_name}.shards.json"), "w") as f:
+                json.dump({"format": "mi355rag-shards-1", "n_total": self.n_total, "d": self.d, "dtype": self.dtype,
+                           "metric": self.metric, "world": self.world}, f)
+        if self.world > 1:
+            self.dist.barrier(group=self.group)
+
+    @classmethod
+    def load_local(cls, folder_path: str, index_name: str = "index", **kwargs) -> "ShardedFlatIndex":
+        """Rebuilds the sharded index on the CURRENT process group: rank r takes rows shard_range(n_total, world, r),
+        read (memory-mapped) from whichever shard files hold them, so a store saved on 8 ranks loads on 1, 2 or 4."""
+        import json
+        import os
+        with open(os.path.join(folder_path, f"{index_name}.shards.json")) as f:
+            meta = json.load(f)
+        if meta.get("format") != "mi355rag-shards-1":
+            raise ValueError(f"{folder_path}: not a mi355rag shard set")
+        sh = cls(meta["d"], metric=meta["metric"], dtype=meta["dtype"], **kwargs)
+        lo, hi = shard_range(meta["n_total"], sh.world, sh.rank)
+        sh.local.set_id_base(lo)
+        slab = max(1, (256 << 20) // (int(meta["d"]) * 4))
+        for r in range(meta["world"]):
+            with open(os.path.join(folder_path, f"{index_name}.shard{r:03d}.json")) as f:
+                part = json.load(f)
+            a, b = max(lo, part["row0"]), min(hi, part["row0"] + part["rows"])
+            if a >= b:
+                continue
+            rows = np.load(os.path.join(folder_path, f"{index_name}.shard{r:03d}.rows.npy"), allow_pickle=False, mmap_mode="r")
+            for r0 in range(a, b, slab):
+                sh.local.add_raw(np.ascontiguousarray(rows[r0 - part["row0"]:min(b, r0 + slab) - part["row0"]]))
+        sh.n_total = meta["n_total"]
+        return sh
+
+
 def embed_sharded(encoder, flat_ids: np.ndarray, offsets: np.ndarray, group=None, gather: bool = True,
                   max_len: int = 0) -> np.ndarray:
     """Data-parallel bulk embedding (BASELINE config 3): every rank is handed the same n ragged sequences (CSR),

@@ -123,6 +123,25 @@ class FlatIndex:
         _capi.check(self._lib.mi_index_get_rows(self._h, int(row0), int(n), _np_ptr(out)))
         return out
 
+    def reconstruct_raw(self, row0: int, n: int) -> np.ndarray:
+        """Rows in the storage type: float32 [n][d], or uint16 bf16 bit patterns [n][d] for a bf16 index."""
+        out = np.empty((n, self.d), dtype=np.float32 if self.dtype == DTYPE_F32 else np.uint16)
+        _capi.check(self._lib.mi_index_get_rows_raw(self._h, int(row0), int(n), _np_ptr(out)))
+        return out
+
+    def add_raw(self, x: np.ndarray) -> None:
+        """Append host rows given as float32 or as uint16 bf16 bit patterns (a shard file's contents)."""
+        if x.dtype == np.uint16:
+            src = DTYPE_BF16
+        elif x.dtype == np.float32:
+            src = DTYPE_F32
+        else:
+            raise ValueError("add_raw: float32 or uint16 (bf16 bit patterns) rows")
+        x = np.ascontiguousarray(x)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError(f"add_raw: expected [n][{self.d}] array, got {x.shape}")
+        _capi.check(self._lib.mi_index_add_raw(self._h, x.shape[0], _np_ptr(x), src))
+
     def reset(self) -> None:
         _capi.check(self._lib.mi_index_reset(self._h))
 

@@ -375,11 +375,24 @@ class MI355VectorStore:
         import os
         os.makedirs(folder_path, exist_ok=True)
         n = self.index.ntotal
-        rows = self.index.reconstruct_n(0, n) if n else np.zeros((0, self.index.d), dtype=np.float32)
         dtype = "bf16" if getattr(self.index, "dtype", 0) == 1 else "f32"
-        if dtype == "bf16":                      # stored values are exactly representable: keep the high halves
-            rows = (rows.view(np.uint32) >> 16).astype(np.uint16)
-        np.save(os.path.join(folder_path, f"{index_name}.rows.npy"), rows, allow_pickle=False)
+        # rows in the storage type (bf16 bit patterns as uint16: the stored values exactly), streamed in slabs into
+        # the .npy file: neither widened to fp32 nor held on the host as a whole
+        npdt = np.uint16 if dtype == "bf16" else np.float32
+        path = os.path.join(folder_path, f"{index_name}.rows.npy")
+        if n and hasattr(self.index, "reconstruct_raw"):
+            mm = np.lib.format.open_memmap(path, mode="w+", dtype=npdt, shape=(n, self.index.d))
+            slab = max(1, (256 << 20) // (self.index.d * 4))
+            for r0 in range(0, n, slab):
+                m = min(slab, n - r0)
+                mm[r0:r0 + m] = self.index.reconstruct_raw(r0, m)
+            mm.flush()
+            del mm
+        else:
+            rows = self.index.reconstruct_n(0, n) if n else np.zeros((0, self.index.d), dtype=np.float32)
+            if dtype == "bf16":                  # stored values are exactly representable: keep the high halves
+                rows = (rows.view(np.uint32) >> 16).astype(np.uint16)
+            np.save(path, rows, allow_pickle=False)
         meta = {"format": "mi355rag-store-1", "d": int(self.index.d), "dtype": dtype,
                 "distance_strategy": self.distance_strategy, "normalize_L2": bool(self._normalize_L2),
                 "ids": [self.index_to_docstore_id[i] for i in range(len(self.index_to_docstore_id))],
@@ -397,14 +410,17 @@ class MI355VectorStore:
             meta = json.load(f)
         if meta.get("format") != "mi355rag-store-1":
             raise ValueError(f"{folder_path}: not a mi355rag store")
-        rows = np.load(os.path.join(folder_path, f"{index_name}.rows.npy"), allow_pickle=False)
-        if meta["dtype"] == "bf16":
-            rows = (rows.astype(np.uint32) << 16).view(np.float32)
+        rows = np.load(os.path.join(folder_path, f"{index_name}.rows.npy"), allow_pickle=False, mmap_mode="r")
         metric = "ip" if meta["distance_strategy"] == MAX_INNER_PRODUCT else "l2"
         make = index_factory or (lambda d, metric, dtype: FlatIndex(d, metric=metric, dtype=dtype, device=device))
         index = make(meta["d"], metric=metric, dtype=meta["dtype"])
-        if len(rows):
-            index.add(np.ascontiguousarray(rows, dtype=np.float32))
+        slab = max(1, (256 << 20) // (int(meta["d"]) * 4))
+        for r0 in range(0, len(rows), slab):
+            part = np.ascontiguousarray(rows[r0:r0 + slab])
+            if hasattr(index, "add_raw"):
+                index.add_raw(part)
+            else:
+                index.add((part.astype(np.uint32) << 16).view(np.float32) if meta["dtype"] == "bf16" else part)
         docs = {k: Document(page_content=v["page_content"], metadata=v["metadata"]) for k, v in meta["documents"].items()}
         return cls(embeddings, index, InMemoryDocstore(docs), {i: _id for i, _id in enumerate(meta["ids"])},
                    normalize_L2=meta["normalize_L2"], distance_strategy=meta["distance_strategy"], **kwargs)

@@ -38,6 +38,13 @@ class OracleIndex:
             x = oracle.bf16_to_f32(oracle.round_bf16(x))
         return np.ascontiguousarray(x, dtype=np.float32)
 
+    def reconstruct_raw(self, row0, n):
+        x = self.X[row0:row0 + n]
+        return oracle.round_bf16(x) if self.dtype == oracle.DTYPE_BF16 else np.ascontiguousarray(x, dtype=np.float32)
+
+    def add_raw(self, x):
+        self.add(oracle.bf16_to_f32(x) if x.dtype == np.uint16 else x)
+
     def reset(self):
         self.X = self.X[:0]
 

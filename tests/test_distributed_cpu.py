@@ -45,6 +45,7 @@ def _worker(rank, world, port, metric, dtype, n, out_dir):
             D, I = sh.search(Q, k)
             np.save(os.path.join(out_dir, f"D_{rank}_{k}.npy"), D)
             np.save(os.path.join(out_dir, f"I_{rank}_{k}.npy"), I)
+        sh.save_local(os.path.join(out_dir, "store"))            # one shard file per rank
     finally:
         dist.destroy_process_group()
 
@@ -66,6 +67,18 @@ def test_two_rank_sharded_search_equals_single_index(tmp_path, oracle_mod, metri
             I = np.load(tmp_path / f"I_{rank}_{k}.npy")
             np.testing.assert_array_equal(I, Iw)
             np.testing.assert_array_equal(D.view(np.uint32), Dw.view(np.uint32))
+    # the per-rank shard files, loaded back on ONE rank (re-sharding on load), give the same answer
+    from rag_amd.distributed import ShardedFlatIndex
+    from tests._fakes import OracleIndex
+    import torch
+    assert sorted(f for f in os.listdir(tmp_path / "store") if f.endswith(".npy")) == ["index.shard000.rows.npy", "index.shard001.rows.npy"]
+    one = ShardedFlatIndex.load_local(str(tmp_path / "store"), local_index=OracleIndex(24, metric, dtype),
+                                      merge_fn=lambda Dm, Im, k, mn: tuple(torch.from_numpy(a) for a in oracle_mod.topk_merge(Dm.numpy(), Im.numpy(), k, m)))
+    assert one.local.ntotal == n and one.n_total == n
+    D1, I1 = one.search(Q, 5)
+    Dw, Iw = oracle_mod.search(X, Q, 5, metric=m, dtype=t)
+    np.testing.assert_array_equal(I1, Iw)
+    np.testing.assert_array_equal(D1.view(np.uint32), Dw.view(np.uint32))
 
 
 def _embed_worker(rank, world, port, n, gather, out_dir):

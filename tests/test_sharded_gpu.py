@@ -121,3 +121,31 @@ def test_merge_beyond_4096_entries_per_query(oracle_mod, nlists, k_in, k):
     Dp, Ip = topk_merge_packed_torch(torch.from_numpy(packed).cuda(), nq, nlists, k_in, k, "ip")
     np.testing.assert_array_equal(Ip.cpu().numpy(), Io)
     np.testing.assert_array_equal(Dp.cpu().numpy().view(np.uint32), Do.view(np.uint32))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_shard_files_round_trip(tmp_path, oracle_mod, dtype):
+    """Per-shard persistence: rows leave in the storage type (bf16 bit patterns, not widened
+    to fp32), a shard file loads back with add_raw, and the reloaded index answers bit for bit like the original."""
+    from rag_amd.distributed import ShardedFlatIndex
+    n, d, k = 40_000, 384, 10
+    sh = ShardedFlatIndex(d, metric="ip", dtype=dtype, device=0)
+    sh.add_synthetic_global(n, seed=71)
+    X = oracle_mod.synth_rows(71, 0, n, d)
+    raw = sh.local.reconstruct_raw(100, 50)
+    if dtype == "bf16":
+        assert raw.dtype == np.uint16
+        np.testing.assert_array_equal(raw, oracle_mod.round_bf16(X[100:150]))
+    else:
+        np.testing.assert_array_equal(raw.view(np.uint32), X[100:150].view(np.uint32))
+    Q = oracle_mod.synth_rows(72, 0, 33, d)
+    D, I = sh.search(Q, k)
+    sh.save_local(str(tmp_path / "s"))
+    sh2 = ShardedFlatIndex.load_local(str(tmp_path / "s"), device=0)
+    assert sh2.local.ntotal == n
+    D2, I2 = sh2.search(Q, k)
+    np.testing.assert_array_equal(I2, I)
+    np.testing.assert_array_equal(D2.view(np.uint32), D.view(np.uint32))
+    m = oracle_mod.DTYPE_BF16 if dtype == "bf16" else oracle_mod.DTYPE_F32
+    Do, Io = oracle_mod.search(X, Q, k, metric=oracle_mod.METRIC_IP, dtype=m)
+    np.testing.assert_array_equal(I, Io)
