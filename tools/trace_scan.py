@@ -7,13 +7,13 @@ import torch
 from rag_amd import _capi
 from rag_amd.index import FlatIndex, MODE_FAST
 
-n = int(float(os.environ.get("N", "100e6"))); nq = int(os.environ.get("Q", "10000"))
-idx = FlatIndex(384, metric="ip", dtype="bf16"); idx.set_mode(MODE_FAST)
+n = int(float(os.environ.get("N", "100e6"))); nq = int(os.environ.get("Q", "10000")); D = int(os.environ.get("D", "384")); K = int(os.environ.get("K", "10"))
+idx = FlatIndex(D, metric="ip", dtype="bf16"); idx.set_mode(MODE_FAST)
 idx.add_synthetic(n, seed=1)
 g = torch.Generator(device="cpu").manual_seed(5)
-q = torch.nn.functional.normalize(torch.randn(nq, 384, generator=g), dim=1).cuda()
+q = torch.nn.functional.normalize(torch.randn(nq, D, generator=g), dim=1).cuda()
 for _ in range(2):
-    D, I = idx.search_torch(q, 10)
+    Dd, I = idx.search_torch(q, K)
 torch.cuda.synchronize()
 print("scan ms", idx.last_scan_time())
 lib = _capi.load()
@@ -26,15 +26,15 @@ for b in range(4):
     print(f"--- workgroup slot {b}")
     per = (t[:, 1:, 0] - t[:, :-1, 0]) & 0xffffffff
     print("unit period per wave (median):", np.median(per, axis=1))
-    kb = (np.arange(64) + 3000) % 3
+    NKB = 6 if D > 384 else (3 if D > 128 else 1); kb = (np.arange(64) + int(os.environ.get("U0", "3000"))) % NKB
     def seg(name, a, b_, sel=None):
         d = (t[:, :, b_] - t[:, :, a]) & 0xffffffff
         if sel is not None: d = d[:, sel]
         print(f"  {name:34s} w0-3 mean {d[:4].mean():7.0f}  w4-7 mean {d[4:].mean():7.0f}  median {np.median(d):7.0f} p90 {np.percentile(d, 90):7.0f}")
     seg("chain", 0, 1)
     seg("issue DMA", 1, 6)
-    seg("filter slot kb<2 (stamp only)", 6, 2, kb != 2)
-    seg("filter slot kb=2", 6, 2, kb == 2)
+    seg("filter slot kb<last (stamp only)", 6, 2, kb != NKB - 1)
+    seg("filter slot kb=last", 6, 2, kb == NKB - 1)
     seg("wait vmcnt", 2, 3)
     seg("barrier", 3, 4)
     d = (t[:, 1:, 0] - t[:, :-1, 4]) & 0xffffffff
