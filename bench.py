@@ -356,7 +356,8 @@ def main() -> int:
                "sample": top["sample"], "legs": [port, blas]}
 
     out = {
-        "metric": "queries/sec exact top-10 @100Mx384 bf16",
+        "metric": ("queries/sec exact top-10 @100Mx384 bf16" if (N, d, k, args.dtype) == (100_000_000, 384, 10, "bf16")
+                   else f"queries/sec exact top-{k} @{N}x{d} {args.dtype}"),
         "value": round(value, 2),
         "unit": "queries/s",
         "n_gpus": ngpu,
