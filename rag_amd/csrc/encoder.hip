@@ -890,10 +890,24 @@ __global__ __launch_bounds__(256) void cvt_pack_w1_kernel(const float* __restric
 
 #ifdef FF_TRACE
 // Debug build only (tools/build_trace.sh): cycle stamps of the phases of eight workgroups of ffn_ln_kernel.
-__device__ uint32_t ff_trace_buf[8][8][16];
+__device__ uint32_t ff_trace_buf[8][8][32];
 #define FF_STAMP(k) do { if (ff_slot >= 0 && lane == 0) ff_trace_buf[ff_slot][wave][k] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+// stamps INSIDE one stage (FF_TRACE_KT): s_memtime into SGPRs without a wait (a wait would drain the fragment reads in
+// flight and change what is measured); written out behind the next stage's own lgkmcnt(0)
+#ifndef FF_TRACE_KT
+#define FF_TRACE_KT 20
+#endif
+// (fixed SGPR pairs s60.. above what the allocator uses: the value lands long after the instruction, so it must not be a
+// register the compiler may copy or reuse)
+#define FF_TICK(k) asm volatile("s_memtime s[%0:%1]" :: "n"(74 + 2 * (k)), "n"(75 + 2 * (k)) : "memory", "s101")
+#define FF_TICK_RD(k, dst) asm volatile("v_mov_b32 %0, s[%1]" : "=v"(dst) : "n"(74 + 2 * (k)))
+#define FF_TICKS_OUT(stage) do { if ((stage) == FF_TRACE_KT && ff_slot >= 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    static_for<14>([&](auto Kc) __attribute__((always_inline)) { uint32_t _v; FF_TICK_RD(decltype(Kc)::value, _v); \
+        if (lane == 0) ff_trace_buf[ff_slot][wave][16 + decltype(Kc)::value] = _v; }); } } while (0)
 #else
 #define FF_STAMP(k) do { } while (0)
+#define FF_TICK(k) do { } while (0)
+#define FF_TICKS_OUT(stage) do { } while (0)
 #endif
 
 // FRONT: the attention output projection + residual + LayerNorm (what gemm_ln_kernel does for K = 384) runs first, on the
@@ -1056,6 +1070,7 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
     for (int kt = 0; kt < nkt; ++kt) {
         // behind this barrier: W2(kt) and W1(kt + 2) have landed for everyone (requested two stages ago),
         // A(kt) is complete, everyone has left stage kt - 1.  In flight: stage kt - 1's requests.
+        FF_TICK(0);
         {
             const int young = (kt >= 1) ? ((kt + 1 < nkt ? 3 : 0) + (kt + 3 < nkt ? 3 : 0)) : (3 < nkt ? 3 : 0);
             if (young == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -1063,7 +1078,10 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        FF_TICKS_OUT(kt - 1);
+        FF_TICK(13);                                               // (13: arrived at the first barrier)
         __builtin_amdgcn_s_barrier();
+        FF_TICK(1);
         const bool more1 = kt + 1 < nkt;                           // A(kt + 1) is still to be written (finish of block kt + 1)
         const bool more2 = kt + 2 < nkt;                           // step 1 of block kt + 2 follows
         const unsigned w2b = w2_rd + (kt % 3) * FF_WS, w1b = w1_rd + ((kt + 2) % 3) * FF_WS;
@@ -1078,7 +1096,9 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(af[0]), "=&v"(af[1]) : "v"(a_rd));
         rd_group(fr[0], w2b);
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0]), "+v"(af[1]));
+        FF_TICK(2);
         __builtin_amdgcn_s_barrier();
+        FF_TICK(3);
         static_for<9>([&](auto Gc) __attribute__((always_inline)) {
             constexpr int g = decltype(Gc)::value;
             if (g < 3 || more2) {
@@ -1109,6 +1129,7 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
             }
             // the finish of block kt + 1, half behind each of the first two MFMA groups
             if constexpr (g < 2) { if (more1) finish_half(g, bb[g]); }
+            FF_TICK(4 + g);
         });
         if (more2) { a1p[0] = a1n[0]; a1p[1] = a1n[1]; }
     }
@@ -1136,6 +1157,382 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
             rres[mb][nb] = *reinterpret_cast<const uint2*>(park + (32 * wm + 16 * mb + l15) * LN_TS + (192 * wn + 16 * nb + 4 * g4) * 2);
     FF_STAMP(7);
     ln_rows_epilogue(lds, prm, acc, rres, out, m0, M, eps, wm, wn, l15, g4);   // (its park writes come two barriers later)
+    FF_STAMP(8);
+#ifdef FF_TRACE
+    if (ff_slot >= 0 && lane == 0) ff_trace_buf[ff_slot][wave][14] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+// ---------------------------------------------------------------- fused FFN, second form (round 2): step 1 split over K
+// Same arithmetic as ffn_ln_kernel, other division of labour.  Cycle stamps of the first form (profiles/r02_ffn_trace.md):
+// a 3,640-cycle stage against 1,536 cycles of matrix pipe per SIMD -- 470 cycles without any MFMA between its two
+// barriers (fragment reads that could not be requested earlier, a vmcnt(0) hipcc put in front of a plain LDS load of
+// b1), six 4-MFMA groups whose fragments (24 ds_read_b128 per wave: every wave read the whole W1 block for its 16 rows)
+// arrive no faster than ~170 cycles per group, the GELU of a block as one VALU run with the wave's MFMAs standing
+// still, and the younger wave of each SIMD 700 cycles behind the older at every barrier.  Here:
+//   * wave (rg, kh) = (wave >> 1, wave & 1) multiplies rows 32 rg .. + 31 (two row blocks) by K half kh of W1_j: 12
+//     fragment reads instead of 24, every fragment feeds two MFMAs, three groups of 8 MFMAs like step 2.  The
+//     partial sums of the partner's row block go through LDS (X, 2 KB per wave), the wave adds the partner's
+//     partial to its own row block (rows 16 wave .. + 15), bias, GELU, bf16 -> A as before;
+//   * one ring of FIVE 24-KB slots holds W2 and W1 blocks in the order they are consumed
+//     (W1_0 W1_1 | W2_0 W1_2 | W2_1 W1_3 | ...), a block is requested when the slot five back is free;
+//   * two barriers per stage, behind groups 0 and 3, each certifying what is needed one group LATER (fragments are
+//     read one group ahead across them), so neither is followed by a dependent LDS read;
+//   * every LDS access of the loop is inline asm (hipcc waits for every LDS-DMA in flight before an LDS load it can see);
+//   * the steady-state stage has no branches; the last four stages are separate instantiations.
+// LDS: 5 x 24 (ring) + 8 (A) + 16 (X) + 6 (b1) KB.
+#define F2_SLOTS 5
+#define F2_RING (F2_SLOTS * FF_WS)
+#define F2_A_OFF F2_RING
+#define F2_X_OFF (F2_A_OFF + 8192)
+#define F2_B1_OFF (F2_X_OFF + 8 * 2048)
+#define F2_LDS_BYTES (F2_B1_OFF + 1536 * 4)
+#define F2_NKT 48                            // intermediate size 1536
+
+template <bool FRONT>
+__global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ h, const uint16_t* __restrict__ W1p,
+        const float* __restrict__ b1, const uint16_t* __restrict__ W2p, const float* __restrict__ b2,
+        const float* __restrict__ gamma, const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M,
+        const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ Wo_p, const float* __restrict__ bo,
+        const float* __restrict__ gamma1, const float* __restrict__ beta1)
+{
+    __shared__ __attribute__((aligned(1024))) char lds[F2_LDS_BYTES];
+    static_assert(F2_LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(F2_RING >= 4096 + 128 * LN_TS + 3 * LN_N * 4, "the epilogue's scratch fits in the ring");
+    static_assert(F2_B1_OFF >= 4 * LN_STAGE + 3 * LN_N * 4, "b1 sits behind the front phase's ring and parameters");
+    constexpr int nkt = F2_NKT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;                       // step 2: row group, column half
+    const int kh = wave & 1;                                       // step 1: K half (row group wm)
+    const int m0 = (int)(gridDim.x - 1 - blockIdx.x) * 128;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+#ifdef FF_TRACE
+    const int ff_slot = (blockIdx.x % 64 == 0 && blockIdx.x / 64 < 8) ? (int)(blockIdx.x / 64) : -1;
+    if (ff_slot >= 0 && lane == 0) ff_trace_buf[ff_slot][wave][15] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
+    FF_STAMP(0);
+
+    for (int i = threadIdx.x; i < 1536 / 4; i += 512)
+        *reinterpret_cast<float4*>(lds + F2_B1_OFF + i * 16) = *reinterpret_cast<const float4*>(b1 + 4 * i);
+    f32x4 acc[2][12];
+    // h fragments (B operand of step 1), k-steps 6 kh .. 6 kh + 5: hqo of the wave's own row block (rows 16 wave + l15),
+    // hqp of the partner's (rows 16 (wave ^ 1) + l15); lane (l15, g4): k = 32 s + 8 g4 ..
+    bf16x8 hqo[6], hqp[6];
+    if constexpr (FRONT) {
+        uint2 rres[2][12];
+        rowgemm384_mainloop(lds, ctx, Wo_p, bo, h, gamma1, beta1, M, LN_N, 1, m0, lane, wave, acc, rres);
+        FF_STAMP(1);
+        ln_rows_epilogue<false>(lds, reinterpret_cast<const float*>(lds + 4 * LN_STAGE), acc, rres, nullptr, m0, M, eps, wm, wn, l15, g4);
+        FF_STAMP(2);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            hqo[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + 4096 + (16 * wave + l15) * LN_TS + (32 * (6 * kh + s) + 8 * g4) * 2));
+            hqp[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + 4096 + (16 * (wave ^ 1) + l15) * LN_TS + (32 * (6 * kh + s) + 8 * g4) * 2));
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) asm volatile("" :: "v"(hqo[s]), "v"(hqp[s]));
+        __syncthreads();                                           // the parked tile gives way to the weight ring
+    } else {
+        int mo = m0 + 16 * wave + l15; if (mo > M - 1) mo = M - 1;
+        int mp = m0 + 16 * (wave ^ 1) + l15; if (mp > M - 1) mp = M - 1;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            hqo[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(h + (int64_t)mo * LN_N + 32 * (6 * kh + s) + 8 * g4));
+            hqp[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(h + (int64_t)mp * LN_N + 32 * (6 * kh + s) + 8 * g4));
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) asm volatile("" :: "v"(hqo[s]), "v"(hqp[s]));
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                               // b1 is in LDS for everyone
+    FF_STAMP(3);
+
+    // ---- LDS-DMA: a block is 24 pieces of 1 KB, wave w issues pieces 3w .. 3w + 2
+    // piece p of a block: 16 rows x 64 B of W2 (lane -> row 16 p + lane / 4, swizzled 16-B slot) or the p-th KB of a W1 block (stored as its LDS image)
+    const char* const w2src = reinterpret_cast<const char*>(W2p) + (lane >> 2) * 64 + (((lane & 3) ^ ((0 - (lane >> 4)) & 3)) * 16);
+    const char* const w1src = reinterpret_cast<const char*>(W1p) + lane * 16;
+    auto dma = [&](const char* src, int j, int slot_off, int piece) __attribute__((always_inline)) {
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + ((int64_t)j * FF_WS + piece * 1024)),
+            (lds_ptr_t)(lds + slot_off + piece * 1024), 16, 0, 0);
+    };
+    auto wrap = [](int o) __attribute__((always_inline)) { return o >= F2_RING ? o - F2_RING : o; };
+    const int rot = wave >> 2;                                     // waves 4-7: one barrier late (see `stage`)
+    const char* const srcD = rot ? w1src : w2src;                  // in the loop waves 0-3 request W2 blocks, waves 4-7 W1 blocks,
+    const int pc0 = 6 * (wave & 3);                                // six pieces per wave
+    const int pp0 = 3 * wave;                                      // prologue: every wave three pieces of every block
+
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[mb][nb][i] = 0.0f;
+
+    const unsigned swz = (unsigned)((0 - (l15 >> 2)) & 3);
+    const unsigned fsw = ((unsigned)g4 ^ swz) << 4;
+    const unsigned a_rd = lds_base + F2_A_OFF + (unsigned)((32 * wm + l15) * 64) + fsw;       // + mb * 1024
+    const unsigned w2_rd = lds_base + (unsigned)((192 * wn + l15) * 64) + fsw;                 // + slot + g * 4096 + q * 1024
+    const unsigned w1_rd = lds_base + (unsigned)(l15 * 64) + fsw + (unsigned)kh * 12288;       // + slot + sp * 4096 + (2 q + cb) * 1024
+    const unsigned a_wr = lds_base + F2_A_OFF + (unsigned)((16 * wave + l15) * 64) + ((((unsigned)g4 >> 1) ^ swz) << 4) + (g4 & 1) * 8;   // cb = 1: ^ 32
+    const unsigned x_wr = lds_base + F2_X_OFF + (unsigned)(wave * 2048 + lane * 16);           // + cb * 1024
+    const unsigned x_rd = lds_base + F2_X_OFF + (unsigned)((wave ^ 1) * 2048 + lane * 16);
+    const unsigned b1_rd = lds_base + F2_B1_OFF + (unsigned)(4 * g4 * 4);                      // + (32 j + 16 cb) * 4
+
+    bf16x8 fr[2][4], af[2];
+    f32x4 Po[2], Pp[2];                                            // step-1 partial sums: own row block, partner's row block
+    f32x4 xr[2], bb[2];
+    auto rd_group = [&](bf16x8 (&d)[4], unsigned base) __attribute__((always_inline)) {
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                     "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(base));
+    };
+    auto rd_af = [&]() __attribute__((always_inline)) {
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(af[0]), "=&v"(af[1]) : "v"(a_rd));
+    };
+    auto rd_xb = [&](int j) __attribute__((always_inline)) {                   // partner's partial + bias of block j
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(xr[0]), "=&v"(xr[1]) : "v"(x_rd));
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64" : "=&v"(bb[0]), "=&v"(bb[1]) : "v"(b1_rd + (unsigned)j * 128u));
+    };
+    auto wr_x = [&]() __attribute__((always_inline)) {
+        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024" :: "v"(x_wr), "v"(Pp[0]), "v"(Pp[1]) : "memory");
+    };
+#define F2_WAIT_FR(N, d) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]))
+    auto wait_fr = [&](auto Nc, bf16x8 (&d)[4]) __attribute__((always_inline)) {
+        constexpr int N = decltype(Nc)::value;
+        static_assert(N == 0 || N == 4 || N == 6 || N == 8, "lgkmcnt");
+        if constexpr (N == 0) F2_WAIT_FR(0, d); else if constexpr (N == 4) F2_WAIT_FR(4, d);
+        else if constexpr (N == 6) F2_WAIT_FR(6, d); else F2_WAIT_FR(8, d);
+    };
+    auto wait_lgkm = [&](auto Nc) __attribute__((always_inline)) {
+        constexpr int N = decltype(Nc)::value;
+        if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else static_assert(N == 0, "lgkmcnt");
+    };
+    auto wait_vm = [&](auto Nc) __attribute__((always_inline)) {
+        constexpr int N = decltype(Nc)::value;
+        if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else static_assert(N < 0, "vmcnt");                        // negative: nothing to wait for
+    };
+    // step 2, group g: 4 W2 fragments (column blocks 4 g .. 4 g + 3) x the two A fragments
+    auto mma2q = [&](bf16x8 (&d)[4], auto Gc, int q0, int q1) __attribute__((always_inline)) {
+        constexpr int g = decltype(Gc)::value;
+#pragma unroll
+        for (int q = q0; q < q1; ++q)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                acc[mb][4 * g + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d[q], af[mb], acc[mb][4 * g + q], 0, 0, 0);
+    };
+    auto mma2 = [&](bf16x8 (&d)[4], auto Gc) __attribute__((always_inline)) { mma2q(d, Gc, 0, 4); };
+    // step 1, group sp: W1 fragments of k-steps 6 kh + 2 sp + q, column blocks cb (d[2 q + cb]) x both row blocks
+    auto mma1 = [&](bf16x8 (&d)[4], auto SPc) __attribute__((always_inline)) {
+        constexpr int sp = decltype(SPc)::value;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                Pp[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d[2 * q + cb], hqp[2 * sp + q], (sp == 0 && q == 0) ? f32x4{} : Pp[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                Po[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d[2 * q + cb], hqo[2 * sp + q], (sp == 0 && q == 0) ? f32x4{} : Po[cb], 0, 0, 0);
+        }
+    };
+    // own partial + partner's partial + bias -> GELU -> bf16 -> A (rows 16 wave + l15, columns 16 cb + 4 g4 ..)
+    f32x4 tv[2];
+    auto fin_sum = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(bb[0]), "+v"(bb[1]));
+        tv[0] = (Po[0] + xr[0]) + bb[0];
+        tv[1] = (Po[1] + xr[1]) + bb[1];
+    };
+    auto fin_half = [&](int cb) __attribute__((always_inline)) {
+        float v0 = tv[cb][0], v1 = tv[cb][1], v2 = tv[cb][2], v3 = tv[cb][3];
+#ifndef F2_ABL_GELU                                                // (F2_ABL_*: timing ablations of the debug build, wrong results)
+        gelu_erf4(v0, v1, v2, v3);
+#endif
+        const uint2 o = make_uint2(pack2(v0, v1), pack2(v2, v3));
+        asm volatile("ds_write_b64 %0, %1" :: "v"(a_wr ^ (cb ? 32u : 0u)), "v"(o) : "memory");
+    };
+#define F2_INTERLEAVE(NV) do { _Pragma("unroll") for (int _i = 0; _i < 8; ++_i) { \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, NV, 0); } } while (0)
+
+    // ---- prologue: blocks 0..4 requested; step 1 of blocks 0 and 1 without overlap; A(0) written
+    {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dma(w1src, 0, 0 * FF_WS, pp0 + i);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dma(w1src, 1, 1 * FF_WS, pp0 + i);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dma(w2src, 0, 2 * FF_WS, pp0 + i);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dma(w1src, 2, 3 * FF_WS, pp0 + i);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dma(w2src, 1, 4 * FF_WS, pp0 + i);
+        wait_vm(IC<9>{});
+        __builtin_amdgcn_s_barrier();                              // W1(0), W1(1) have landed for everyone
+        FF_STAMP(4);
+        auto step1_all = [&](unsigned wb) __attribute__((always_inline)) {
+            rd_group(fr[0], wb);
+            rd_group(fr[1], wb + 4096);
+            wait_fr(IC<4>{}, fr[0]); mma1(fr[0], IC<0>{});
+            rd_group(fr[0], wb + 8192);
+            wait_fr(IC<4>{}, fr[1]); mma1(fr[1], IC<1>{});
+            wait_fr(IC<0>{}, fr[0]); mma1(fr[0], IC<2>{});
+        };
+        step1_all(w1_rd + 0 * FF_WS);
+        wr_x();
+        wait_lgkm(IC<0>{});
+        __builtin_amdgcn_s_barrier();                              // X(0) is written
+        rd_xb(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(bb[0]), "+v"(bb[1]));
+        tv[0] = (Po[0] + xr[0]) + bb[0];
+        tv[1] = (Po[1] + xr[1]) + bb[1];
+        fin_half(0); fin_half(1);
+        step1_all(w1_rd + 1 * FF_WS);
+        wait_vm(IC<0>{});                                          // W2(0), W1(2), W2(1): the loop's own waits cover only what it requests
+        wait_lgkm(IC<0>{});
+        __builtin_amdgcn_s_barrier();                              // A(0) complete, X(0) consumed, W2(0) landed, slots 0 and 1 free
+        rd_af();
+        rd_group(fr[0], w2_rd + 2 * FF_WS);
+        wr_x();                                                    // X(1)
+    }
+    FF_STAMP(5);
+
+    // One stage of a wave.  Groups 0-2: step 2 of block kt (W2(kt) in slot off2); groups 3-5: step 1 of block kt + 2
+    // (W1(kt + 2) in slot off1).  Barrier "alpha" behind group 0: X(kt + 1) is written.  Barrier "beta" behind group 2:
+    // A(kt + 1) is written, X(kt + 1) consumed.  Between alpha and beta a wave has 16 MFMAs and the GELU of a block
+    // (~100 VALU instructions, which its own MFMAs do not hide: an in-order wave pays for both); between beta and the next
+    // alpha it has 32 MFMAs and requests a quarter of a weight block (six LDS-DMA pieces at 60-180 cycles of issue each).
+    // Waves 4-7 (rot = 1) run the same program ONE BARRIER LATE, so on every SIMD one wave is in the first kind of
+    // interval while the other is in the second, and the two intervals cost a wave about the same time.
+    // The ring is kept by the count of hardware barriers b_0, b_1, ... (alpha(kt) = b_{2 kt + rot}, beta(kt) = b_{2 kt + 1 + rot}):
+    // every wave has left block i behind b_i, so block i + 5 is requested right behind b_i -- by the four waves for which b_i
+    // is a beta: waves 0-3 request the W2 blocks, waves 4-7 the W1 blocks -- and its requesters wait for it before they arrive
+    // at b_{i+2}, their next beta (vmcnt(0): nothing else of theirs is in flight); the first read of block i + 5 comes behind b_{i+2}.
+    // Flags: S1 step 1 of block kt + 2 exists, FIN block kt + 1 exists.
+    auto stage = [&](int kt, int off2, int off1, auto S1c, auto FINc) __attribute__((always_inline)) {
+        constexpr bool S1 = decltype(S1c)::value != 0, FIN = decltype(FINc)::value != 0;
+        const int off2n = wrap(off2 + 2 * FF_WS);                  // slot of W2(kt + 1)
+        const int jD = rot ? kt + 4 : kt + 2;                      // behind beta: W1(kt + 4) into the slot of W2(kt) / W2(kt + 2) into that of W1(kt + 1)
+        const int slotD = rot ? off2 : wrap(off2 + 4 * FF_WS);
+#ifdef F2_ABL_DMA
+        const bool doD = false;
+#else
+        const bool doD = jD < nkt;
+#endif
+        FF_TICK(0);
+        // ---- group 0
+        rd_group(fr[1], w2_rd + off2 + 4096);
+        wait_fr(IC<(FIN ? 6 : 4)>{}, fr[0]);                        // younger: X write (2), group 1 (4)
+        asm volatile("" : "+v"(af[0]), "+v"(af[1]));
+        mma2(fr[0], IC<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FIN) wait_lgkm(IC<4>{});                      // the X write is done
+        FF_TICK(1);
+        __builtin_amdgcn_s_barrier();                              // alpha
+        FF_TICK(2);
+        // ---- group 1
+        if constexpr (FIN) rd_xb(kt + 1);
+        rd_group(fr[0], w2_rd + off2 + 8192);
+        wait_fr(IC<(FIN ? 8 : 4)>{}, fr[1]);
+        mma2q(fr[1], IC<1>{}, 0, 2);                               // four MFMAs cover the partner's partial on its way from LDS
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FIN) fin_sum();
+        mma2q(fr[1], IC<1>{}, 2, 4);
+        if constexpr (FIN) { fin_half(0); F2_INTERLEAVE(12); }
+        __builtin_amdgcn_sched_barrier(0);
+        FF_TICK(3);
+        // ---- group 2
+        if constexpr (S1) rd_group(fr[1], w1_rd + off1);
+        wait_fr(IC<(S1 ? 4 : 0)>{}, fr[0]);
+        mma2(fr[0], IC<2>{});
+        if constexpr (FIN) { fin_half(1); F2_INTERLEAVE(6); }
+        __builtin_amdgcn_sched_barrier(0);
+        FF_TICK(4);
+        wait_lgkm(IC<0>{});                                        // the A write is done
+        wait_vm(IC<0>{});                                          // and the pieces requested behind the previous beta have landed
+        FF_TICK(5);
+        __builtin_amdgcn_s_barrier();                              // beta
+        FF_TICK(6);
+        // ---- group 3
+        if constexpr (S1) {
+            rd_group(fr[0], w1_rd + off1 + 4096);
+            wait_fr(IC<4>{}, fr[1]);
+            mma1(fr[1], IC<0>{});
+        }
+        if (doD) { dma(srcD, jD, slotD, pc0 + 0); dma(srcD, jD, slotD, pc0 + 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- group 4
+        if constexpr (S1) {
+            rd_group(fr[1], w1_rd + off1 + 8192);
+            wait_fr(IC<4>{}, fr[0]);
+            mma1(fr[0], IC<1>{});
+        }
+        if (doD) { dma(srcD, jD, slotD, pc0 + 2); dma(srcD, jD, slotD, pc0 + 3); }
+        __builtin_amdgcn_sched_barrier(0);
+        FF_TICK(7);
+        // ---- group 5
+        if constexpr (FIN) { rd_af(); rd_group(fr[0], w2_rd + off2n); }        // block kt + 1 exists: its step 2 follows
+        if constexpr (S1) {
+            wait_fr(IC<(FIN ? 6 : 0)>{}, fr[1]);
+            mma1(fr[1], IC<2>{});
+            wr_x();                                                // X(kt + 2)
+        }
+        if (doD) { dma(srcD, jD, slotD, pc0 + 4); dma(srcD, jD, slotD, pc0 + 5); }
+        __builtin_amdgcn_sched_barrier(0);
+        FF_TICK(8);
+    };
+
+    {
+        int off2 = 2 * FF_WS, off1 = 3 * FF_WS;
+        int kt = 0;
+        if (rot) {                                                 // b_0: the older half's first alpha
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dma(w1src, 3, 0 * FF_WS, pc0 + i);     // block 5 = W1(3), behind b_0
+        }
+        for (; kt < nkt - 2; ++kt) {
+            FF_TICKS_OUT(kt - 1);
+            stage(kt, off2, off1, IC<1>{}, IC<1>{});
+            off2 = wrap(off2 + 2 * FF_WS);
+            off1 = wrap(off1 + 2 * FF_WS);
+        }
+        stage(kt, off2, off1, IC<0>{}, IC<1>{});                   // nkt - 2
+        off2 = wrap(off2 + 2 * FF_WS); off1 = wrap(off1 + 2 * FF_WS); ++kt;
+        stage(kt, off2, off1, IC<0>{}, IC<0>{});                   // nkt - 1
+        if (!rot) __builtin_amdgcn_s_barrier();                    // the younger half's last beta
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                               // the ring becomes the epilogue's scratch
+    FF_STAMP(6);
+
+    float* const prm = reinterpret_cast<float*>(lds + 4096 + 128 * LN_TS);
+    if (threadIdx.x < 3 * LN_N / 4) {
+        const int which = threadIdx.x / (LN_N / 4), o = (threadIdx.x % (LN_N / 4)) * 4;
+        const float* srcp = which == 0 ? b2 : which == 1 ? gamma : beta;
+        *reinterpret_cast<float4*>(prm + which * LN_N + o) = *reinterpret_cast<const float4*>(srcp + o);
+    }
+    // the residual is the tile of h the workgroup holds (step-1 layout): through LDS into the epilogue's layout
+    char* const park = lds + 4096;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        *reinterpret_cast<uint4*>(park + (16 * wave + l15) * LN_TS + (32 * (6 * kh + s) + 8 * g4) * 2) = __builtin_bit_cast(uint4, hqo[s]);
+        *reinterpret_cast<uint4*>(park + (16 * (wave ^ 1) + l15) * LN_TS + (32 * (6 * kh + s) + 8 * g4) * 2) = __builtin_bit_cast(uint4, hqp[s]);
+    }
+    __syncthreads();
+    uint2 rres[2][12];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb)
+            rres[mb][nb] = *reinterpret_cast<const uint2*>(park + (32 * wm + 16 * mb + l15) * LN_TS + (192 * wn + 16 * nb + 4 * g4) * 2);
+    FF_STAMP(7);
+    ln_rows_epilogue(lds, prm, acc, rres, out, m0, M, eps, wm, wn, l15, g4);
     FF_STAMP(8);
 #ifdef FF_TRACE
     if (ff_slot >= 0 && lane == 0) ff_trace_buf[ff_slot][wave][14] = (uint32_t)__builtin_amdgcn_s_memrealtime();
@@ -1772,12 +2169,19 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     const bool fused_ffn = fused_ln && !ffn_off && I == 1536;
     static const bool front_off = getenv("MI_FFN_FRONT") && atoi(getenv("MI_FFN_FRONT")) == 0;
     const bool fused_front = fused_ffn && !front_off;
+    // MI_FFN2=0: the first form of the fused FFN (ffn_ln_kernel) instead of the K-split one (ffn2_kernel); read per call (A/B)
+    const bool ffn2 = !(getenv("MI_FFN2") && atoi(getenv("MI_FFN2")) == 0);
     MI_HIP(hipEventRecord(e->ev0, st));
     if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, types, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, types, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     for (const LayerW& lw : e->layers) {
         const bool qkv_blocked = launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H, true);
         attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, scale_log2e, qkv_blocked ? 1 : 0, fused_ln ? 1 : 0);
+        if (fused_front && ffn2) {
+            ffn2_kernel<true><<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T,
+                                                                           ctx, lw.Wo_p, lw.bo, lw.g1, lw.b1);
+            continue;
+        }
         if (fused_front) {
             // attention output projection + LayerNorm + FFN + LayerNorm in one kernel per 128-row tile
             ffn_ln_kernel<true><<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I,
@@ -1790,6 +2194,11 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
             launch_gemm<EPI_RESID>(st, ctx, lw.Wo, lw.bo, h, tmp, (int)T, H, H);
             if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
             else add_ln_kernel<2><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
+        }
+        if (fused_ffn && ffn2) {
+            ffn2_kernel<false><<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T,
+                                                                            nullptr, nullptr, nullptr, nullptr, nullptr);
+            continue;
         }
         if (fused_ffn) {
             ffn_ln_kernel<false><<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I,
