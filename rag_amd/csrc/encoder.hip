@@ -37,6 +37,8 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short tr4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) tr4_t tr4_lds_t;
 
 template <int V> using IC = std::integral_constant<int, V>;
 template <int... I, class F>
@@ -1548,11 +1550,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
         uint16_t* __restrict__ ctx, int L, int Lp, int H, float scale_log2e, int qkv_blocked, int ctx_blocked)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // Ks [Lp][64 B] swizzled | Vt [32][Lp*2 + 8 B] | maskf [Lp]
+    // Ks [Lp][64 B] swizzled | Vs [Lp][64 B] | maskf [Lp]
     char* Ks = smem;
-    const int vt_stride = Lp * 2 + 8;
-    char* Vt = smem + (size_t)Lp * 64;
-    float* maskf = reinterpret_cast<float*>(Vt + 32 * vt_stride);
+    char* Vs = smem + (size_t)Lp * 64;
+    float* maskf = reinterpret_cast<float*>(Vs + (size_t)Lp * 64);
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -1580,12 +1581,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
             vv = *reinterpret_cast<const uint4*>(qkv_at(key, 2, c));
         }
         *reinterpret_cast<uint4*>(Ks + key * 64 + ((c ^ ((key >> 2) & 3)) << 4)) = kv;
-        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const uint16_t val = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
-            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + e) * vt_stride + key * 2) = val;
-        }
+        *reinterpret_cast<uint4*>(Vs + key * 64 + c * 16) = vv;      // row-major: the transposed fragments come from ds_read_b64_tr_b16
     }
     for (int key = t; key < Lp; key += 256)
         maskf[key] = (key < L && mask[(int64_t)b * L + key] != 0) ? 0.0f : -FLT_MAX;
@@ -1624,13 +1620,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
         for (int g = 0; g < 4; ++g) mk[g] = *reinterpret_cast<const float4*>(maskf + 32 * kb + 8 * g + 4 * hp);
         // V^T fragments (A operand of the PV product): row = dh (col), element j <-> key
         // 32 kb + 16 s + 8 (j >> 2) + 4 hp + (j & 3)
+        // by the hardware transpose read: a 16-lane group reads 4 keys x 16 dh, lane 4 q + p supplies the address of key q,
+        // dh 4 p .., and lane i receives dh i of the 4 keys -- conflict-free on plain 64-B rows, and V is staged with
+        // four 16-B stores per thread instead of 32 two-byte ones
         bf16x8 vf[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const char* vp = Vt + col * vt_stride + (32 * kb + 16 * s + 4 * hp) * 2;
-            const uint2 lo = *reinterpret_cast<const uint2*>(vp);
-            const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
-            vf[s] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            const char* vp = Vs + (32 * kb + 16 * s + 4 * hp + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+            const tr4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t*)(vp));
+            const tr4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t*)(vp + 8 * 64));
+            vf[s] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
@@ -1657,8 +1656,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
             for (int i = 2; i < 7; ++i) bm = __builtin_fmaxf(__builtin_fmaxf(bm, t2[i].y), t2[i + 1].x);
             bm = __builtin_fmaxf(bm, t2[7].y);
             bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-            const float m_new = fmaxf(m_run[nb], bm);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_new);
+            // The running maximum only guards the exponent range: it moves (and O, l are rescaled) only when some lane's
+            // block maximum exceeds it by more than 2^8 -- after the first key blocks almost never, and the 16-register
+            // multiply of O leaves the VALU-bound loop.  p <= 2^8 is exact in fp32 and bf16 alike; the final 1 / l
+            // takes the same reference.  (-inf start: the first block always moves it.)
+            float m_new = m_run[nb];
+            if (__builtin_amdgcn_ballot_w64(bm > m_run[nb] + 8.0f) != 0) {
+                m_new = fmaxf(m_run[nb], bm);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_new);
+                l_run[nb] *= alpha;
+                O[nb] = O[nb] * alpha;
+                m_run[nb] = m_new;
+            }
             const f32x2 mn2 = {m_new, m_new};
             f32x2 ps2 = {0.0f, 0.0f};
             float p[16];
@@ -1671,9 +1680,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
                 ps2 = ps2 + e2;
                 p[2 * i] = e2.x; p[2 * i + 1] = e2.y;
             }
-            l_run[nb] = l_run[nb] * alpha + (ps2.x + ps2.y);
-            m_run[nb] = m_new;
-            O[nb] = O[nb] * alpha;
+            l_run[nb] += ps2.x + ps2.y;
             // P^T as B operand: k-step s takes registers 8 s .. 8 s + 7
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -2149,7 +2156,7 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
 
     const unsigned tok_grid = (unsigned)((T + 3) / 4);
     const int Lp = (L + 31) / 32 * 32;
-    const size_t attn_smem = (size_t)Lp * 64 + 32 * ((size_t)Lp * 2 + 8) + (size_t)Lp * 4;
+    const size_t attn_smem = (size_t)Lp * 128 + (size_t)Lp * 4;      // K rows, V rows, additive mask
     if (attn_smem > 96 * 1024) { mi_set_error("encode: sequence length %d too long for the attention kernel", L); return MI_ERR_UNSUPPORTED; }
     const float scale_log2e = (1.0f / sqrtf(32.0f)) * 1.4426950408889634f;
 
