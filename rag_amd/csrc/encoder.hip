@@ -1298,7 +1298,8 @@ __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ 
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64" : "=&v"(bb[0]), "=&v"(bb[1]) : "v"(b1_rd + (unsigned)j * 128u));
     };
     auto wr_x = [&]() __attribute__((always_inline)) {
-        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024" :: "v"(x_wr), "v"(Pp[0]), "v"(Pp[1]) : "memory");
+        // (Pp comes straight out of the MFMAs and hipcc does not see an inline-asm reader: the wait states are written out)
+        asm volatile("s_nop 15\n\ts_nop 3\n\tds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024" :: "v"(x_wr), "v"(Pp[0]), "v"(Pp[1]) : "memory");
     };
 #define F2_WAIT_FR(N, d) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]))
     auto wait_fr = [&](auto Nc, bf16x8 (&d)[4]) __attribute__((always_inline)) {
@@ -1546,8 +1547,8 @@ __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ 
 // S^T = K Q^T (keys on accumulator rows, the query on the lane), so max/sum over keys are
 // in-register plus one cross-half exchange; P (bf16) feeds O^T = V^T P^T directly as the B
 // operand (the accumulator-as-operand k-permutation is matched by the V^T fragment reads).
-__global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
-        uint16_t* __restrict__ ctx, int L, int Lp, int H, float scale_log2e, int qkv_blocked, int ctx_blocked)
+__global__ __launch_bounds__(256, 4) void attn_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
+        uint16_t* __restrict__ ctx, int L, int Lp, int H, int qkv_blocked, int ctx_blocked)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // Ks [Lp][64 B] swizzled | Vs [Lp][64 B] | maskf [Lp]
@@ -1599,13 +1600,26 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
         for (int s = 0; s < 2; ++s)
             qf[nb][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qkv_at(q, 0, 2 * s + hp)));
     }
+    // Scores arrive in log2 units: dh^-1/2 log2(e) is folded into Wq and bq when the weights are loaded.  A lane holds one
+    // query (column) and 16 keys of the block.  m_run is the exponent reference of the running softmax; it only has to keep
+    // exp2 in range, so it moves (and O, Ls are rescaled) only when a block's maximum exceeds it by more than 2^8 (p <= 2^8 is
+    // as exact in fp32 and bf16 as p <= 1; the final 1 / l takes the same reference).
+    // The loop is VALU-bound (16 v_exp_f32 at quarter rate per 32 x 32 block are most of it): the additive mask is the C
+    // operand of the first QK^T MFMA, everything else runs two values per instruction (v_pk_add_f32) or three (v_max3_f32).
+    // (Row sums by a third MFMA against an all-ones operand were measured too: 16 VALU instructions less per block, but 32
+    // more registers -- three workgroups per CU instead of four, 53.5 against 50.9 us.)
     float m_run[2] = {-__builtin_inff(), -__builtin_inff()};
-    float l_run[2] = {0.0f, 0.0f};
     f32x16 O[2];
+    f32x2 ps2[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};              // running row sums (this lane's keys, even / odd registers)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) O[nb][i] = 0.0f;
+    auto max3 = [](float a, float b2, float c) __attribute__((always_inline)) {
+        float r;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b2), "v"(c));
+        return r;
+    };
 
     const int ksw = (col >> 2) & 3;
     for (int kb = 0; kb < Lp / 32; ++kb) {
@@ -1614,12 +1628,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
 #pragma unroll
         for (int s = 0; s < 2; ++s)
             kf[s] = *reinterpret_cast<const bf16x8*>(Ks + (32 * kb + col) * 64 + (((2 * s + hp) ^ ksw) << 4));
-        // additive mask of the 16 keys this lane's registers hold: key = 32 kb + 8 g + 4 hp + e
-        float4 mk[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) mk[g] = *reinterpret_cast<const float4*>(maskf + 32 * kb + 8 * g + 4 * hp);
-        // V^T fragments (A operand of the PV product): row = dh (col), element j <-> key
-        // 32 kb + 16 s + 8 (j >> 2) + 4 hp + (j & 3)
+        // V^T fragments (A operand of the PV product): row = dh (col), element j <-> key 32 kb + 16 s + 8 (j >> 2) + 4 hp + (j & 3),
         // by the hardware transpose read: a 16-lane group reads 4 keys x 16 dh, lane 4 q + p supplies the address of key q,
         // dh 4 p .., and lane i receives dh i of the 4 keys -- conflict-free on plain 64-B rows, and V is staged with
         // four 16-B stores per thread instead of 32 two-byte ones
@@ -1631,61 +1640,55 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
             const tr4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr4_lds_t*)(vp + 8 * 64));
             vf[s] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
+        // additive mask of the 16 keys this lane's registers hold: key = 32 kb + 8 g + 4 hp + e; 0 or -FLT_MAX (finite, as the
+        // reference's finfo.min: a masked score stays at -FLT_MAX, so an all-masked row softmaxes to uniform)
+        f32x16 MK;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 mk = *reinterpret_cast<const float4*>(maskf + 32 * kb + 8 * g + 4 * hp);
+            MK[4 * g + 0] = mk.x; MK[4 * g + 1] = mk.y; MK[4 * g + 2] = mk.z; MK[4 * g + 3] = mk.w;
+        }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
-            f32x16 S;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) S[i] = 0.0f;
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[nb][0], S, 0, 0, 0);
+            f32x16 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[nb][0], MK, 0, 0, 0);        // score + mask
             S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[nb][1], S, 0, 0, 0);
-            // scores in log2 units: s * (dh^-1/2 * log2 e) + mask, mask = 0 or -FLT_MAX (finite, as in
-            // the reference's additive finfo.min mask: the fma leaves a masked score at -FLT_MAX, so an
-            // all-masked row softmaxes to uniform)
-            // (two values per instruction where the ISA has a packed fp32 form: the kernel is VALU-bound)
-            f32x2 t2[8];
-            const f32x2 sc2 = {scale_log2e, scale_log2e};
+            // d = S - m_run, two per instruction; the block maximum is taken of d (8 v_max3 written out: they read the
+            // results of the subtraction, never an MFMA's directly -- hipcc pads MFMA results only for readers it can see)
+            f32x2 d2[8];
+            {
+                const f32x2 mn2 = {m_run[nb], m_run[nb]};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x2 s2 = {S[2 * i], S[2 * i + 1]};
-                const f32x2 m2 = (i & 1) ? f32x2{mk[i >> 1].z, mk[i >> 1].w} : f32x2{mk[i >> 1].x, mk[i >> 1].y};
-                t2[i] = __builtin_elementwise_fma(s2, sc2, m2);
+                for (int i = 0; i < 8; ++i) d2[i] = f32x2{S[2 * i], S[2 * i + 1]} - mn2;
             }
-            float bm = __builtin_fmaxf(__builtin_fmaxf(t2[0].x, t2[0].y), t2[1].x);
-            bm = __builtin_fmaxf(__builtin_fmaxf(bm, t2[1].y), t2[2].x);
-#pragma unroll
-            for (int i = 2; i < 7; ++i) bm = __builtin_fmaxf(__builtin_fmaxf(bm, t2[i].y), t2[i + 1].x);
-            bm = __builtin_fmaxf(bm, t2[7].y);
+            float bm = max3(max3(d2[0].x, d2[0].y, d2[1].x), max3(d2[1].y, d2[2].x, d2[2].y), max3(d2[3].x, d2[3].y, d2[4].x));
+            bm = max3(bm, max3(d2[4].y, d2[5].x, d2[5].y), max3(d2[6].x, d2[6].y, d2[7].x));
+            bm = fmaxf(bm, d2[7].y);
             bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-            // The running maximum only guards the exponent range: it moves (and O, l are rescaled) only when some lane's
-            // block maximum exceeds it by more than 2^8 -- after the first key blocks almost never, and the 16-register
-            // multiply of O leaves the VALU-bound loop.  p <= 2^8 is exact in fp32 and bf16 alike; the final 1 / l
-            // takes the same reference.  (-inf start: the first block always moves it.)
-            float m_new = m_run[nb];
-            if (__builtin_amdgcn_ballot_w64(bm > m_run[nb] + 8.0f) != 0) {
-                m_new = fmaxf(m_run[nb], bm);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_new);
-                l_run[nb] *= alpha;
-                O[nb] = O[nb] * alpha;
-                m_run[nb] = m_new;
-            }
-            const f32x2 mn2 = {m_new, m_new};
-            f32x2 ps2 = {0.0f, 0.0f};
-            float p[16];
+            if (__builtin_amdgcn_ballot_w64(!(bm <= 8.0f)) != 0) {          // rare (the first block: m_run = -inf, d = +inf): move the reference exactly
+                float tm = fmaxf(fmaxf(S[0], S[1]), S[2]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f32x2 d2 = t2[i] - mn2;
-                f32x2 e2;
-                e2.x = __builtin_amdgcn_exp2f(d2.x);
-                e2.y = __builtin_amdgcn_exp2f(d2.y);
-                ps2 = ps2 + e2;
-                p[2 * i] = e2.x; p[2 * i + 1] = e2.y;
+                for (int i = 3; i < 16; ++i) tm = fmaxf(tm, S[i]);
+                tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+                const float m_new = fmaxf(m_run[nb], tm);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_new);
+                O[nb] = O[nb] * alpha;
+                ps2[nb] = ps2[nb] * alpha;
+                m_run[nb] = m_new;
+                const f32x2 mn2 = {m_new, m_new};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) d2[i] = f32x2{S[2 * i], S[2 * i + 1]} - mn2;
             }
-            l_run[nb] += ps2.x + ps2.y;
             // P^T as B operand: k-step s takes registers 8 s .. 8 s + 7
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const uint4 pk = make_uint4(pack2(p[8 * s + 0], p[8 * s + 1]), pack2(p[8 * s + 2], p[8 * s + 3]),
-                                            pack2(p[8 * s + 4], p[8 * s + 5]), pack2(p[8 * s + 6], p[8 * s + 7]));
+                f32x2 e2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    e2[i].x = __builtin_amdgcn_exp2f(d2[4 * s + i].x);
+                    e2[i].y = __builtin_amdgcn_exp2f(d2[4 * s + i].y);
+                    ps2[nb] = ps2[nb] + e2[i];
+                }
+                const uint4 pk = make_uint4(pack2(e2[0].x, e2[0].y), pack2(e2[1].x, e2[1].y), pack2(e2[2].x, e2[2].y), pack2(e2[3].x, e2[3].y));
                 O[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s], __builtin_bit_cast(bf16x8, pk), O[nb], 0, 0, 0);
             }
         }
@@ -1693,8 +1696,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const uint16_t* __restrict
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const int q = q0 + 32 * nb + col;
-        const float lt = l_run[nb] + __shfl_xor(l_run[nb], 32, 64);
-        const float inv = 1.0f / lt;
+        const float lh = ps2[nb].x + ps2[nb].y;
+        const float inv = 1.0f / (lh + __shfl_xor(lh, 32, 64));
         if (q < L) {
             const int64_t tg = tok0 + q;
             uint16_t* dst = ctx_blocked ? ctx + (((tg >> 7) * nblk_c + head) * 128 + (tg & 127)) * 32
@@ -1799,9 +1802,15 @@ __global__ __launch_bounds__(256) void cvt_pack32_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int64_t n)
+__global__ __launch_bounds__(256) void scale_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int n, float scale)
 {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = mi_f32_to_bf16(in[i]);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i] * scale;
+}
+
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int64_t n, float scale)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = mi_f32_to_bf16(in[i] * scale);
 }
 
 
@@ -1978,9 +1987,12 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
     e->eg = p; p += H;
     e->eb = p; p += H;
     uint16_t* w = e->wbf;
-    auto cvt = [&](const float* src, uint16_t* dst, int64_t n) {
-        cvt_bf16_kernel<<<(unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096), 256, 0, e->stream>>>(src, dst, n);
+    auto cvt = [&](const float* src, uint16_t* dst, int64_t n, float scale = 1.0f) {
+        cvt_bf16_kernel<<<(unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096), 256, 0, e->stream>>>(src, dst, n, scale);
     };
+    // attention scores in log2 units straight out of the QK^T MFMA: dh^-1/2 * log2(e) is folded into Wq and bq (modeling_bert.py:
+    // scores / sqrt(head size), then softmax; attn_kernel exponentiates with exp2).  One fp32 multiply before the bf16 rounding.
+    const float qscale = (1.0f / sqrtf((float)(H / cfg->num_attention_heads))) * 1.4426950408889634f;
     for (int l = 0; l < cfg->num_hidden_layers; ++l) {
         LayerW lw{};
         // blob: Wq bq Wk bk Wv bv Wo bo g1 b1 Wi bi Wd bd g2 b2 ; fused QKV needs Wq|Wk|Wv rows back to back
@@ -1993,7 +2005,7 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
         float* Wd = bi + I; float* bd = Wd + (int64_t)H * I;
         float* g2 = bd + H; float* b2 = g2 + H;
         p = b2 + H;
-        lw.Wqkv = w; cvt(Wq, w, (int64_t)H * H); cvt(Wk, w + (int64_t)H * H, (int64_t)H * H); cvt(Wv, w + 2 * (int64_t)H * H, (int64_t)H * H);
+        lw.Wqkv = w; cvt(Wq, w, (int64_t)H * H, qscale); cvt(Wk, w + (int64_t)H * H, (int64_t)H * H); cvt(Wv, w + 2 * (int64_t)H * H, (int64_t)H * H);
         w += 3 * (int64_t)H * H;
         lw.Wo = w; cvt(Wo, w, (int64_t)H * H); w += (int64_t)H * H;
         lw.Wi = w; cvt(Wi, w, (int64_t)I * H); w += (int64_t)I * H;
@@ -2007,7 +2019,7 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
         lw.bo = bo; lw.bi = bi; lw.bd = bd; lw.g1 = g1; lw.b1 = b1; lw.g2 = g2; lw.b2 = b2;
         e->layers.push_back(lw);                       // owned by e from here on (encoder_free releases bqkv)
         ENC_HIP(me);
-        ENC_HIP(hipMemcpyAsync(lw.bqkv, bq, (size_t)H * 4, hipMemcpyDeviceToDevice, e->stream));
+        scale_f32_kernel<<<(unsigned)((H + 255) / 256), 256, 0, e->stream>>>(bq, lw.bqkv, H, qscale);
         ENC_HIP(hipMemcpyAsync(lw.bqkv + H, bk, (size_t)H * 4, hipMemcpyDeviceToDevice, e->stream));
         ENC_HIP(hipMemcpyAsync(lw.bqkv + 2 * H, bv, (size_t)H * 4, hipMemcpyDeviceToDevice, e->stream));
     }
@@ -2158,7 +2170,6 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     const int Lp = (L + 31) / 32 * 32;
     const size_t attn_smem = (size_t)Lp * 128 + (size_t)Lp * 4;      // K rows, V rows, additive mask
     if (attn_smem > 96 * 1024) { mi_set_error("encode: sequence length %d too long for the attention kernel", L); return MI_ERR_UNSUPPORTED; }
-    const float scale_log2e = (1.0f / sqrtf(32.0f)) * 1.4426950408889634f;
 
     // hidden size 384: the two N = 384 projections run fused with their LayerNorm (MI_GEMM_LN=0: separate kernels)
     static const bool ln_off = getenv("MI_GEMM_LN") && atoi(getenv("MI_GEMM_LN")) == 0;
@@ -2183,7 +2194,7 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, types, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     for (const LayerW& lw : e->layers) {
         const bool qkv_blocked = launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H, true);
-        attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, scale_log2e, qkv_blocked ? 1 : 0, fused_ln ? 1 : 0);
+        attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, qkv_blocked ? 1 : 0, fused_ln ? 1 : 0);
         if (fused_front && ffn2) {
             ffn2_kernel<true><<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T,
                                                                            ctx, lw.Wo_p, lw.bo, lw.g1, lw.b1);
