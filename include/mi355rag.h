@@ -164,6 +164,24 @@ int  mi_topk_packed_layout(int64_t nq, int k, size_t* ids_offset, size_t* block_
 int  mi_topk_merge_packed_dev(mi_ctx* ctx, int metric, int64_t nq, int nlists, int k_in, const void* packed_dev,
                               int k, float* out_scores_dev, int64_t* out_ids_dev, void* stream);
 
+/* ------------------------------------------------------------------ communicator (multi-GPU hosts without torch.distributed)
+ * The reference has no multi-GPU path; rag_amd/distributed.py runs the sharded search over
+ * torch.distributed.  These entry points give a C / Go / Java host the same three steps over RCCL (loaded with dlopen at
+ * the first call; MI355RAG_RCCL overrides the library path).  One process per GPU: rank 0 calls mi_comm_unique_id and
+ * hands the 128 bytes to the other ranks by its own means, every rank calls mi_comm_create (collective), then
+ * mi_index_search_sharded_dev = mi_index_search_dev into the rank's packed block -> ONE ncclAllGather of block_bytes ->
+ * mi_topk_merge_packed_dev; every rank returns the identical, exact answer.  Rank r's index holds the contiguous rows
+ * [r * ceil(N / G), ...) with mi_index_set_id_base.  q_dev must be identical on every rank. */
+typedef struct mi_comm mi_comm;
+int  mi_comm_unique_id(void* out_id128);
+int  mi_comm_create(mi_ctx* ctx, const void* id128, int nranks, int rank, mi_comm** out);
+void mi_comm_destroy(mi_comm* comm);
+int  mi_comm_size(const mi_comm* comm);
+int  mi_comm_rank(const mi_comm* comm);
+int  mi_comm_all_gather_dev(mi_comm* comm, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+int  mi_index_search_sharded_dev(mi_index* idx, mi_comm* comm, int64_t nq, const float* q_dev, int k,
+                                 float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+
 /* ------------------------------------------------------------------ encoder
  * Replaces HuggingFaceEmbeddings(...).embed_documents / embed_query
  * (advanced_rag.py:104-107; sentence-transformers -> transformers BertModel,

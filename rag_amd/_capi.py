@@ -71,6 +71,13 @@ SYMBOLS = {
     "mi_topk_merge_dev": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mi_topk_packed_layout": (_i32, [_i64, _i32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "mi_topk_merge_packed_dev": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "mi_comm_unique_id": (_i32, [_vp]),
+    "mi_comm_create": (_i32, [_vp, _vp, _i32, _i32, _pp]),
+    "mi_comm_destroy": (None, [_vp]),
+    "mi_comm_size": (_i32, [_vp]),
+    "mi_comm_rank": (_i32, [_vp]),
+    "mi_comm_all_gather_dev": (_i32, [_vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "mi_index_search_sharded_dev": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     "mi_encoder_blob_elems": (_i64, [_cfgp]),
     "mi_encoder_create": (_i32, [_vp, _cfgp, _vp, ctypes.c_size_t, _pp]),
     "mi_encoder_destroy": (None, [_vp]),

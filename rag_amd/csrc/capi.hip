@@ -791,3 +791,133 @@ extern "C" int mi_topk_merge_packed_dev(mi_ctx* ctx, int metric, int64_t nq, int
                      (int64_t)(block / sizeof(float)), (int64_t)(block / sizeof(int64_t)), k_in, k_in, k_in};
     return merge_any(ctx, st, metric, nq, m, in, k, out_scores_dev, out_ids_dev);
 }
+
+// ---------------------------------------------------------------- communicator (SURVEY.md section 8e for a host without torch.distributed)
+// RCCL is loaded with dlopen at the first mi_comm_* call, so the library has no link-time dependency on it and a
+// single-GPU host never touches it; an absent librccl is a loud MI_ERR_UNSUPPORTED.  One communicator = one rank = one
+// process with one GPU; the caller moves the 128-byte unique id between its processes however it likes (file, socket, MPI).
+#include <dlfcn.h>
+namespace {
+struct RcclId { char internal[128]; };
+typedef int (*fn_get_unique_id)(RcclId*);
+typedef int (*fn_comm_init_rank)(void**, int, RcclId, int);
+typedef int (*fn_all_gather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_comm_destroy)(void*);
+typedef const char* (*fn_error_string)(int);
+struct Rccl {
+    void* h = nullptr;
+    fn_get_unique_id get_unique_id = nullptr;
+    fn_comm_init_rank comm_init_rank = nullptr;
+    fn_all_gather all_gather = nullptr;
+    fn_comm_destroy comm_destroy = nullptr;
+    fn_error_string error_string = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+int rccl_load()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.h) return MI_OK;
+    const char* names[] = {getenv("MI355RAG_RCCL"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) { mi_set_error("mi_comm: librccl.so not found (set MI355RAG_RCCL to its path): %s", dlerror()); return MI_ERR_UNSUPPORTED; }
+    Rccl r;
+    r.h = h;
+    r.get_unique_id = (fn_get_unique_id)dlsym(h, "ncclGetUniqueId");
+    r.comm_init_rank = (fn_comm_init_rank)dlsym(h, "ncclCommInitRank");
+    r.all_gather = (fn_all_gather)dlsym(h, "ncclAllGather");
+    r.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
+    r.error_string = (fn_error_string)dlsym(h, "ncclGetErrorString");
+    if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy) {
+        mi_set_error("mi_comm: the RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy");
+        dlclose(h);
+        return MI_ERR_UNSUPPORTED;
+    }
+    g_rccl = r;
+    return MI_OK;
+}
+int rccl_fail(const char* what, int rc)
+{
+    mi_set_error("%s failed: %s", what, g_rccl.error_string ? g_rccl.error_string(rc) : "RCCL error");
+    return MI_ERR_HIP;
+}
+}  // namespace
+
+struct mi_comm {
+    mi_ctx* ctx = nullptr;
+    void* comm = nullptr;
+    int nranks = 1, rank = 0;
+    std::mutex mu;
+    DevBuf mine, gathered;        // this rank's packed block, the rank-major blocks of all ranks (grow-only)
+};
+
+extern "C" int mi_comm_unique_id(void* out_id128)
+{
+    MI_REQUIRE(out_id128, "mi_comm_unique_id: NULL argument");
+    MI_TRY(rccl_load());
+    RcclId id;
+    const int rc = g_rccl.get_unique_id(&id);
+    if (rc != 0) return rccl_fail("ncclGetUniqueId", rc);
+    memcpy(out_id128, &id, sizeof(id));
+    return MI_OK;
+}
+
+extern "C" int mi_comm_create(mi_ctx* ctx, const void* id128, int nranks, int rank, mi_comm** out)
+{
+    MI_REQUIRE(ctx && id128 && out && nranks >= 1 && rank >= 0 && rank < nranks, "mi_comm_create: bad argument");
+    MI_TRY(rccl_load());
+    DeviceGuard guard(ctx->device);
+    mi_comm* c = new (std::nothrow) mi_comm();
+    if (!c) { mi_set_error("mi_comm_create: out of host memory"); return MI_ERR_OOM; }
+    c->ctx = ctx; c->nranks = nranks; c->rank = rank;
+    RcclId id;
+    memcpy(&id, id128, sizeof(id));
+    const int rc = g_rccl.comm_init_rank(&c->comm, nranks, id, rank);
+    if (rc != 0) { delete c; return rccl_fail("ncclCommInitRank", rc); }
+    *out = c;
+    return MI_OK;
+}
+
+extern "C" void mi_comm_destroy(mi_comm* c)
+{
+    if (!c) return;
+    DeviceGuard guard(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) (void)g_rccl.comm_destroy(c->comm);
+    c->mine.release();
+    c->gathered.release();
+    delete c;
+}
+
+extern "C" int mi_comm_size(const mi_comm* c) { return c ? c->nranks : -1; }
+extern "C" int mi_comm_rank(const mi_comm* c) { return c ? c->rank : -1; }
+
+extern "C" int mi_comm_all_gather_dev(mi_comm* c, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream)
+{
+    MI_REQUIRE(c && send_dev && recv_dev, "mi_comm_all_gather_dev: NULL argument");
+    DeviceGuard guard(c->ctx->device);
+    hipStream_t st = mi_pick_stream(stream, c->ctx->stream);
+    const int rc = g_rccl.all_gather(send_dev, recv_dev, bytes_per_rank, /* ncclUint8 */ 1, c->comm, st);
+    if (rc != 0) return rccl_fail("ncclAllGather", rc);
+    return MI_OK;
+}
+
+// The whole sharded search of one rank: local exact top-k into the rank's packed block -> ONE all-gather -> the same
+// deterministic merge on every rank (rag_amd/distributed.py does the same three steps over torch.distributed).
+extern "C" int mi_index_search_sharded_dev(mi_index* idx, mi_comm* c, int64_t nq, const float* q_dev, int k,
+                                           float* out_scores_dev, int64_t* out_ids_dev, void* stream)
+{
+    MI_REQUIRE(idx && c && q_dev && out_scores_dev && out_ids_dev && nq > 0 && k > 0, "mi_index_search_sharded_dev: bad argument");
+    MI_REQUIRE(idx->ctx == c->ctx, "mi_index_search_sharded_dev: the index and the communicator belong to different contexts");
+    DeviceGuard guard(c->ctx->device);
+    std::lock_guard<std::mutex> lk(c->mu);
+    size_t ids_off = 0, block = 0;
+    MI_TRY(mi_topk_packed_layout(nq, k, &ids_off, &block));
+    MI_TRY(c->mine.ensure(block));
+    MI_TRY(c->gathered.ensure(block * (size_t)c->nranks));
+    char* mine = (char*)c->mine.p;
+    MI_TRY(mi_index_search_dev(idx, nq, q_dev, k, (float*)mine, (int64_t*)(mine + ids_off), stream));
+    MI_TRY(mi_comm_all_gather_dev(c, mine, c->gathered.p, block, stream));
+    return mi_topk_merge_packed_dev(c->ctx, idx->metric, nq, c->nranks, k, c->gathered.p, k, out_scores_dev, out_ids_dev, stream);
+}
