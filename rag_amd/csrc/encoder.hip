@@ -37,6 +37,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef short tr4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) tr4_t tr4_lds_t;
 
@@ -607,6 +608,35 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
     if (active && ntiles > 0) store_tile(ntiles - 1);
 }
 
+#ifdef FF_TRACE
+// Debug build only (tools/build_trace.sh): cycle stamps of the phases of eight workgroups of ffn_ln_kernel.
+__device__ uint32_t ff_trace_buf[8][8][48];
+#define FF_STAMP(k) do { if (ff_slot >= 0 && lane == 0) ff_trace_buf[ff_slot][wave][k] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
+// stamps INSIDE one stage (FF_TRACE_KT): s_memtime into SGPRs without a wait (a wait would drain the fragment reads in
+// flight and change what is measured); written out behind the next stage's own lgkmcnt(0)
+#ifndef FF_TRACE_KT
+#define FF_TRACE_KT 20
+#endif
+// (fixed SGPR pairs s60.. above what the allocator uses: the value lands long after the instruction, so it must not be a
+// register the compiler may copy or reuse)
+#define FF_TICK(k) asm volatile("s_memtime s[%0:%1]" :: "n"(74 + 2 * (k)), "n"(75 + 2 * (k)) : "memory", "s101")
+#define FF_TICK_RD(k, dst) asm volatile("v_mov_b32 %0, s[%1]" : "=v"(dst) : "n"(74 + 2 * (k)))
+#define FF_TICKS_OUT_AT(base, cond) do { if ((cond) && ff_slot >= 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    static_for<14>([&](auto Kc) __attribute__((always_inline)) { uint32_t _v; FF_TICK_RD(decltype(Kc)::value, _v); \
+        if (lane == 0) ff_trace_buf[ff_slot][wave][(base) + decltype(Kc)::value] = _v; }); } } while (0)
+#define FF_TICKS_OUT(stage) FF_TICKS_OUT_AT(16, (stage) == FF_TRACE_KT)
+// the stages of the front GEMM (rowgemm384_mainloop, K = 384: twelve): tick kt at the top of stage kt
+#define FF_TICK_STAGE(kt) do { switch (kt) { case 0: FF_TICK(0); break; case 1: FF_TICK(1); break; case 2: FF_TICK(2); break; \
+    case 3: FF_TICK(3); break; case 4: FF_TICK(4); break; case 5: FF_TICK(5); break; case 6: FF_TICK(6); break; case 7: FF_TICK(7); break; \
+    case 8: FF_TICK(8); break; case 9: FF_TICK(9); break; case 10: FF_TICK(10); break; case 11: FF_TICK(11); break; default: break; } } while (0)
+#else
+#define FF_STAMP(k) do { } while (0)
+#define FF_TICK(k) do { } while (0)
+#define FF_TICKS_OUT(stage) do { } while (0)
+#define FF_TICKS_OUT_AT(base, cond) do { } while (0)
+#define FF_TICK_STAGE(kt) do { } while (0)
+#endif
+
 #define LN_N 384
 #define LN_TS 784                            // parked bf16 row: 384 columns + 8 pad
 // ---- shared epilogue of the row-complete kernels: bias + residual, LayerNorm over the 384 columns, bf16 rows out.
@@ -716,23 +746,31 @@ __device__ __forceinline__ void rowgemm384_mainloop(char* lds, const uint16_t* _
     // ds_read_b128 is served in (rows {0-3, 12-15} of one k-chunk and rows 4-11 of the next) each
     // touch all 64 banks once.  Wave w issues pieces 4w..4w+3 (waves 0, 1: the A rows).
     const int nkt = K / 32;                                        // even (K is a multiple of 64), >= 12
-    // bias / gamma / beta live in LDS for the epilogue (36 dependent float4 global loads there cost microseconds per tile)
+    // bias / gamma / beta live in LDS for the epilogue (36 dependent float4 global loads there cost microseconds per tile): one
+    // 16-B load per thread < 288, the OLDEST request of the wave, stored behind the first wait below.
     float* const prm = reinterpret_cast<float*>(lds + 4 * LN_STAGE);
-    if (threadIdx.x < 3 * LN_N / 4) {
+    const bool has_p = threadIdx.x < 3 * LN_N / 4;
+    f32x4 pv = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (has_p) {
         const int which = threadIdx.x / (LN_N / 4), o = (threadIdx.x % (LN_N / 4)) * 4;
-        const float* srcp = which == 0 ? bias : which == 1 ? gamma : beta;
-        *reinterpret_cast<float4*>(prm + which * LN_N + o) = *reinterpret_cast<const float4*>(srcp + o);
+        const float* srcp = (which == 0 ? bias : which == 1 ? gamma : beta) + o;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(pv) : "v"(srcp));
     }
-    // The residual rows (8 bytes per lane per accumulator block) are requested during the first
-    // stage and sit in registers until the epilogue: fetched there they cost ~5 us per tile.
+    // The residual tile is 128 whole rows = 96 KB contiguous: 12 coalesced 16-B loads per thread (chunk c = t + 512 i, row c / 48),
+    // requested behind the first three stages, in registers through the main loop, and turned into the epilogue's layout
+    // through LDS at the end.  (Round 1 fetched it in the epilogue's layout, 24 loads of 8 B per lane from 16 rows each,
+    // behind stage 0: stamps showed the waves ~7,000 cycles in stage 1 issuing them -- front GEMM 29,000 -> 24,800 cycles.
+    // Requested behind stage 2 instead, the 12 loads stall stage 3 for 5,000 cycles: 26,500.)
+    u32x4 rt[12];
     auto prefetch_resid = [&]() __attribute__((always_inline)) {
+        int row = threadIdx.x / 48, cc = threadIdx.x % 48;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            int m = m0 + 32 * wm + 16 * mb + l15; if (m > M - 1) m = M - 1;
-            const uint16_t* rp = resid + (int64_t)m * LN_N + 192 * wn + 4 * g4;
-#pragma unroll
-            for (int nb = 0; nb < 12; ++nb)
-                asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=&v"(rres[mb][nb]) : "v"(rp), "n"(nb * 32));
+        for (int i = 0; i < 12; ++i) {
+            int m = m0 + row; if (m > M - 1) m = M - 1;
+            const uint16_t* rp = resid + (int64_t)m * LN_N + cc * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rt[i]) : "v"(rp));
+            row += 10; cc += 32;                                   // + 512 chunks = 10 rows + 32 chunks
+            if (cc >= 48) { cc -= 48; row += 1; }
         }
     };
     const int64_t rowbytes = (int64_t)K * 2;
@@ -797,6 +835,7 @@ __device__ __forceinline__ void rowgemm384_mainloop(char* lds, const uint16_t* _
     // PAR = parity of the stage's first group (3 groups per stage: it alternates)
     auto stage = [&](int kt, auto PARc) __attribute__((always_inline)) {
         constexpr int P = decltype(PARc)::value;
+        FF_TICK_STAGE(kt);
         bf16x8 (&a2)[2] = af[P];                                   // the stage's A fragments arrived with its group 0
         rd_w(wf[P ^ 1], kt, 1);
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[P][0]), "+v"(wf[P][1]), "+v"(wf[P][2]), "+v"(wf[P][3]), "+v"(a2[0]), "+v"(a2[1]));
@@ -804,13 +843,12 @@ __device__ __forceinline__ void rowgemm384_mainloop(char* lds, const uint16_t* _
         rd_w(wf[P], kt, 2);
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wf[P ^ 1][0]), "+v"(wf[P ^ 1][1]), "+v"(wf[P ^ 1][2]), "+v"(wf[P ^ 1][3]));
         mma(wf[P ^ 1], a2, 1);
-        // in flight behind stage kt + 1: stage kt + 2 (4 loads) and, in stage 1, the 24 residual loads
-        // (requested behind the barrier of stage 0; stage 2's wait retires them: they are older than stage 3)
-        if (kt == 1) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+        // in flight behind stage kt + 1: stage kt + 2 (4 loads) and, in stages 0 and 1, the 12 residual loads (requested behind
+        // stage 2, older than stage 3: stage 2's wait retires them)
+        if (kt < 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt == 0) prefetch_resid();                             // younger than stages 0..2, older than stage 3
         if (kt + 3 < nkt) issue(kt + 3);
         if (kt + 1 < nkt) {
             rd_a(af[P ^ 1], kt + 1);
@@ -822,12 +860,10 @@ __device__ __forceinline__ void rowgemm384_mainloop(char* lds, const uint16_t* _
         mma(wf[P], a2, 2);
     };
 
-    issue(0);
-    if (nkt > 1) issue(1);
-    if (nkt > 2) issue(2);
-    if (nkt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue(0); issue(1); issue(2);                                  // (nkt >= 12: K is a multiple of 64 and >= 384)
+    prefetch_resid();
+    asm volatile("s_waitcnt vmcnt(20)" : "+v"(pv) :: "memory");     // stage 0 (and the parameter load before it); in flight: stages 1, 2, residual
+    if (has_p) *reinterpret_cast<f32x4*>(prm + (threadIdx.x / (LN_N / 4)) * LN_N + (threadIdx.x % (LN_N / 4)) * 4) = pv;
     __builtin_amdgcn_s_barrier();
     rd_a(af[0], 0);
     rd_w(wf[0], 0, 0);
@@ -836,7 +872,25 @@ __device__ __forceinline__ void rowgemm384_mainloop(char* lds, const uint16_t* _
         stage(kt + 1, IC<1>{});
     }
     __syncthreads();                                               // the ring becomes the epilogue's scratch
-
+    // the residual tile: registers (contiguous chunks) -> LDS rows of LN_TS bytes -> the epilogue's layout
+    {
+        char* const park = lds + 4096;
+        int row = threadIdx.x / 48, cc = threadIdx.x % 48;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            asm volatile("" : "+v"(rt[i]));
+            *reinterpret_cast<u32x4*>(park + row * LN_TS + cc * 16) = rt[i];
+            row += 10; cc += 32;
+            if (cc >= 48) { cc -= 48; row += 1; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 12; ++nb)
+                rres[mb][nb] = *reinterpret_cast<const uint2*>(park + (32 * wm + 16 * mb + l15) * LN_TS + (192 * wn + 16 * nb + 4 * g4) * 2);
+        __syncthreads();                                           // (the epilogue parks its output in the same rows)
+    }
 }
 
 
@@ -890,27 +944,6 @@ __global__ __launch_bounds__(256) void cvt_pack_w1_kernel(const float* __restric
     }
 }
 
-#ifdef FF_TRACE
-// Debug build only (tools/build_trace.sh): cycle stamps of the phases of eight workgroups of ffn_ln_kernel.
-__device__ uint32_t ff_trace_buf[8][8][32];
-#define FF_STAMP(k) do { if (ff_slot >= 0 && lane == 0) ff_trace_buf[ff_slot][wave][k] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
-// stamps INSIDE one stage (FF_TRACE_KT): s_memtime into SGPRs without a wait (a wait would drain the fragment reads in
-// flight and change what is measured); written out behind the next stage's own lgkmcnt(0)
-#ifndef FF_TRACE_KT
-#define FF_TRACE_KT 20
-#endif
-// (fixed SGPR pairs s60.. above what the allocator uses: the value lands long after the instruction, so it must not be a
-// register the compiler may copy or reuse)
-#define FF_TICK(k) asm volatile("s_memtime s[%0:%1]" :: "n"(74 + 2 * (k)), "n"(75 + 2 * (k)) : "memory", "s101")
-#define FF_TICK_RD(k, dst) asm volatile("v_mov_b32 %0, s[%1]" : "=v"(dst) : "n"(74 + 2 * (k)))
-#define FF_TICKS_OUT(stage) do { if ((stage) == FF_TRACE_KT && ff_slot >= 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    static_for<14>([&](auto Kc) __attribute__((always_inline)) { uint32_t _v; FF_TICK_RD(decltype(Kc)::value, _v); \
-        if (lane == 0) ff_trace_buf[ff_slot][wave][16 + decltype(Kc)::value] = _v; }); } } while (0)
-#else
-#define FF_STAMP(k) do { } while (0)
-#define FF_TICK(k) do { } while (0)
-#define FF_TICKS_OUT(stage) do { } while (0)
-#endif
 
 // FRONT: the attention output projection + residual + LayerNorm (what gemm_ln_kernel does for K = 384) runs first, on the
 // same 128 rows: h is then the layer's input (the residual of that LayerNorm), its result never goes to HBM -- it is
@@ -1216,8 +1249,6 @@ __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ 
 #endif
     FF_STAMP(0);
 
-    for (int i = threadIdx.x; i < 1536 / 4; i += 512)
-        *reinterpret_cast<float4*>(lds + F2_B1_OFF + i * 16) = *reinterpret_cast<const float4*>(b1 + 4 * i);
     f32x4 acc[2][12];
     // h fragments (B operand of step 1), k-steps 6 kh .. 6 kh + 5: hqo of the wave's own row block (rows 16 wave + l15),
     // hqp of the partner's (rows 16 (wave ^ 1) + l15); lane (l15, g4): k = 32 s + 8 g4 ..
@@ -1226,6 +1257,7 @@ __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ 
         uint2 rres[2][12];
         rowgemm384_mainloop(lds, ctx, Wo_p, bo, h, gamma1, beta1, M, LN_N, 1, m0, lane, wave, acc, rres);
         FF_STAMP(1);
+        FF_TICKS_OUT_AT(32, true);
         ln_rows_epilogue<false>(lds, reinterpret_cast<const float*>(lds + 4 * LN_STAGE), acc, rres, nullptr, m0, M, eps, wm, wn, l15, g4);
         FF_STAMP(2);
 #pragma unroll
@@ -1366,6 +1398,9 @@ __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ 
 
     // ---- prologue: blocks 0..4 requested; step 1 of blocks 0 and 1 without overlap; A(0) written
     {
+        // b1 -> LDS rides along: loaded ahead of the block requests, stored behind them (first read behind the second barrier below)
+        float4 b1v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (threadIdx.x < 1536 / 4) b1v = *reinterpret_cast<const float4*>(b1 + 4 * threadIdx.x);
 #pragma unroll
         for (int i = 0; i < 3; ++i) dma(w1src, 0, 0 * FF_WS, pp0 + i);
 #pragma unroll
@@ -1376,6 +1411,7 @@ __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ 
         for (int i = 0; i < 3; ++i) dma(w1src, 2, 3 * FF_WS, pp0 + i);
 #pragma unroll
         for (int i = 0; i < 3; ++i) dma(w2src, 1, 4 * FF_WS, pp0 + i);
+        if (threadIdx.x < 1536 / 4) *reinterpret_cast<float4*>(lds + F2_B1_OFF + threadIdx.x * 16) = b1v;
         wait_vm(IC<9>{});
         __builtin_amdgcn_s_barrier();                              // W1(0), W1(1) have landed for everyone
         FF_STAMP(4);

@@ -11,12 +11,14 @@ cfg = BertConfig(vocab_size=30522, hidden_size=384, num_hidden_layers=6, num_att
                  max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12, normalize=1)
 blob = random_blob(cfg, seed=0, init_range=0.02)
 rng = np.random.default_rng(0)
-ids = rng.integers(0, 30522, size=(256, 256)).astype(np.int32); mask = np.ones((256, 256), np.int32)
+NSEQ = int(os.environ.get("NSEQ", "256"))                     # sequences of 256 tokens (256 = 64K tokens = 512 row tiles: two per CU)
+ids = rng.integers(0, 30522, size=(NSEQ, 256)).astype(np.int32); mask = np.ones((NSEQ, 256), np.int32)
+os.environ["MI_ENC_LATENCY_TOKENS"] = "0"
 enc = Encoder(cfg, blob)
 for _ in range(3): enc.encode_ids(ids, mask)
 print("encode ms (64K tokens):", enc.last_time_ms())
 lib = _capi.load()
-buf = np.zeros((8, 8, 32), np.uint32)
+buf = np.zeros((8, 8, 48), np.uint32)
 lib.mi_debug_read_ff_trace.argtypes = [ctypes.c_void_p]
 assert lib.mi_debug_read_ff_trace(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 t = buf.astype(np.int64)
@@ -62,3 +64,10 @@ if os.environ.get("MI_FFN2", "1") != "0":
         base = tk[sl, :, 2].min()
         for j, k in enumerate(ev2):
             print(f"  {evn2[j]:10s} " + " ".join(f"{int(x - base):6d}" for x in tk[sl, :, k]))
+
+if os.environ.get("MI_FFN2", "1") != "0":
+    print("front GEMM: top of stage kt relative to the kernel's first stamp (slot 0, waves 0..7):")
+    fr = t[0, :, 32:44]
+    for kt in range(12):
+        print(f"  stage {kt:2d} " + " ".join(f"{int((x - t[0, w, 0]) & 0xffffffff):6d}" for w, x in enumerate(fr[:, kt])))
+    print("  end      " + " ".join(f"{int((t[0, w, 1] - t[0, w, 0]) & 0xffffffff):6d}" for w in range(8)))
