@@ -1504,7 +1504,9 @@ __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ 
             wait_fr(IC<4>{}, fr[1]);
             mma1(fr[1], IC<0>{});
         }
+        FF_TICK(9);
         if (doD) { dma(srcD, jD, slotD, pc0 + 0); dma(srcD, jD, slotD, pc0 + 1); }
+        FF_TICK(10);
         __builtin_amdgcn_sched_barrier(0);
         // ---- group 4
         if constexpr (S1) {
@@ -1512,7 +1514,9 @@ __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ 
             wait_fr(IC<4>{}, fr[0]);
             mma1(fr[0], IC<1>{});
         }
+        FF_TICK(11);
         if (doD) { dma(srcD, jD, slotD, pc0 + 2); dma(srcD, jD, slotD, pc0 + 3); }
+        FF_TICK(12);
         __builtin_amdgcn_sched_barrier(0);
         FF_TICK(7);
         // ---- group 5

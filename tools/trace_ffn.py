@@ -58,8 +58,8 @@ for sl in (0, 3):
         print(f"  {evn[j]:9s} " + " ".join(f"{int(x - base):6d}" for x in tk[sl, :, k]))
 if os.environ.get("MI_FFN2", "1") != "0":
     print("ffn2 stage timeline relative to the release of barrier alpha (rows: events, columns: waves 0..7), slots 0 and 3:")
-    ev2 = [0, 1, 2, 3, 4, 5, 6, 7, 8]
-    evn2 = ["top", "at alpha", "past alpha", "g1 done", "g2 done", "at beta", "past beta", "g4 done", "g5 done"]
+    ev2 = [0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 7, 8]
+    evn2 = ["top", "at alpha", "past alpha", "g1 done", "g2 done", "at beta", "past beta", "g3 mfma'd", "+2 DMA", "g4 mfma'd", "+2 DMA", "g4 done", "g5 done"]
     for sl in (0, 3):
         base = tk[sl, :, 2].min()
         for j, k in enumerate(ev2):
