@@ -1293,8 +1293,15 @@ __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ 
     };
     auto wrap = [](int o) __attribute__((always_inline)) { return o >= F2_RING ? o - F2_RING : o; };
     const int rot = wave >> 2;                                     // waves 4-7: one barrier late (see `stage`)
-    const char* const srcD = rot ? w1src : w2src;                  // in the loop waves 0-3 request W2 blocks, waves 4-7 W1 blocks,
-    const int pc0 = 6 * (wave & 3);                                // six pieces per wave
+    // in the loop waves 0-3 request W2 blocks, waves 4-7 W1 blocks, six pieces per wave, with the base address in SGPRs and one
+    // constant 32-bit lane offset (the builtin takes a 64-bit vector address: a 64-bit vector add per piece)
+    const char* const baseD = reinterpret_cast<const char*>(rot ? W1p : W2p);
+    const unsigned voffD = rot ? (unsigned)(lane * 16) : (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((0 - (lane >> 4)) & 3)) * 16));
+    auto dma_s = [&](int j, int slot_off, int piece) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(voffD), "s"(baseD + ((int64_t)j * FF_WS + piece * 1024)), "s"(lds_base + (unsigned)(slot_off + piece * 1024)) : "memory", "m0");
+    };
+    const int pc0 = 6 * (wave & 3);
     const int pp0 = 3 * wave;                                      // prologue: every wave three pieces of every block
 
 #pragma unroll
@@ -1505,7 +1512,7 @@ __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ 
             mma1(fr[1], IC<0>{});
         }
         FF_TICK(9);
-        if (doD) { dma(srcD, jD, slotD, pc0 + 0); dma(srcD, jD, slotD, pc0 + 1); }
+        if (doD) { dma_s(jD, slotD, pc0 + 0); dma_s(jD, slotD, pc0 + 1); }
         FF_TICK(10);
         __builtin_amdgcn_sched_barrier(0);
         // ---- group 4
@@ -1515,7 +1522,7 @@ __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ 
             mma1(fr[0], IC<1>{});
         }
         FF_TICK(11);
-        if (doD) { dma(srcD, jD, slotD, pc0 + 2); dma(srcD, jD, slotD, pc0 + 3); }
+        if (doD) { dma_s(jD, slotD, pc0 + 2); dma_s(jD, slotD, pc0 + 3); }
         FF_TICK(12);
         __builtin_amdgcn_sched_barrier(0);
         FF_TICK(7);
@@ -1526,7 +1533,7 @@ __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ 
             mma1(fr[1], IC<2>{});
             wr_x();                                                // X(kt + 2)
         }
-        if (doD) { dma(srcD, jD, slotD, pc0 + 4); dma(srcD, jD, slotD, pc0 + 5); }
+        if (doD) { dma_s(jD, slotD, pc0 + 4); dma_s(jD, slotD, pc0 + 5); }
         __builtin_amdgcn_sched_barrier(0);
         FF_TICK(8);
     };
