@@ -2142,12 +2142,98 @@ static bool launch_gemm_ws(hipStream_t st, const uint16_t* A, const uint16_t* W,
     return true;
 }
 
+// ---------------------------------------------------------------- skinny GEMM: M <= 128 rows (a query, a few chunks)
+// C[M][N] = epilogue(A[M][K] W[N][K]^T + bias (+ resid)) for the call sizes of embed_query (advanced_rag.py:296 embeds the
+// query before every search): the general kernel's 128 x 128 tiles leave a 16-token query with 3 to 12 workgroups that
+// each walk K in dependent stages (6-11 us per GEMM, 214 of the 280 us of a query).  Here a wave owns 16 output columns
+// and a K range of 384: its W fragments (12 k-steps) and the x fragments of 32 rows are requested in one go, straight into
+// registers -- one memory round trip, then 12-24 MFMAs.  K = 384: the four waves of a workgroup take four column blocks;
+// K = 1536 (KSPLIT = 4): they share one column block, each a quarter of K, and wave 0 adds the partial sums through LDS.
+// More than 32 rows: blockIdx.y walks the groups of 32 rows, side by side (W comes from L2 again; still one round trip).
+template <int EPI, int KSPLIT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+        const float* __restrict__ bias, const uint16_t* __restrict__ resid, uint16_t* __restrict__ C, int M, int N, int K)
+{
+    __shared__ float red[3][2][64][4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int n0 = KSPLIT == 1 ? ((int)blockIdx.x * 4 + wave) * 16 : (int)blockIdx.x * 16;
+    const int k0 = KSPLIT == 1 ? 0 : wave * 384;
+    bf16x8 wf[12];
+    {
+        const uint16_t* wp = W + (int64_t)(n0 + l15) * K + k0 + 8 * g4;
+#pragma unroll
+        for (int s = 0; s < 12; ++s) wf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wp + 32 * s));
+    }
+    {
+        const int m0 = (int)blockIdx.y * 32;                        // 32 rows per workgroup row: all row groups run side by side
+        const bool two = M - m0 > 16;                               // (uniform) a second block of 16 rows
+        bf16x8 xf[2][12];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            if (mb == 0 || two) {
+                int m = m0 + 16 * mb + l15; if (m > M - 1) m = M - 1;
+                const uint16_t* xp = A + (int64_t)m * K + k0 + 8 * g4;
+#pragma unroll
+                for (int s = 0; s < 12; ++s) xf[mb][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xp + 32 * s));
+            }
+        }
+        f32x4 acc[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf[0][s], acc[0], 0, 0, 0);
+            if (two) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], xf[1][s], acc[1], 0, 0, 0);
+        }
+        if constexpr (KSPLIT > 1) {
+            if (wave > 0) {
+                *reinterpret_cast<f32x4*>(&red[wave - 1][0][lane][0]) = acc[0];
+                *reinterpret_cast<f32x4*>(&red[wave - 1][1][lane][0]) = acc[1];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    acc[0] += *reinterpret_cast<const f32x4*>(&red[w][0][lane][0]);
+                    acc[1] += *reinterpret_cast<const f32x4*>(&red[w][1][lane][0]);
+                }
+            }
+        }
+        if (KSPLIT == 1 || wave == 0) {
+            // lane (l15, g4): row m0 + 16 mb + l15, columns n0 + 4 g4 .. + 3
+            const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + 4 * g4);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int m = m0 + 16 * mb + l15;
+                if ((mb == 0 || two) && m < M) {
+                    float v0 = acc[mb][0] + bv.x, v1 = acc[mb][1] + bv.y, v2 = acc[mb][2] + bv.z, v3 = acc[mb][3] + bv.w;
+                    if constexpr (EPI == EPI_GELU) gelu_erf4(v0, v1, v2, v3);
+                    if constexpr (EPI == EPI_RESID) {
+                        const uint2 rv = *reinterpret_cast<const uint2*>(resid + (int64_t)m * N + n0 + 4 * g4);
+                        v0 += __builtin_bit_cast(float, rv.x << 16); v1 += __builtin_bit_cast(float, rv.x & 0xFFFF0000u);
+                        v2 += __builtin_bit_cast(float, rv.y << 16); v3 += __builtin_bit_cast(float, rv.y & 0xFFFF0000u);
+                    }
+                    *reinterpret_cast<uint2*>(C + (int64_t)m * N + n0 + 4 * g4) = make_uint2(pack2(v0, v1), pack2(v2, v3));
+                }
+            }
+        }
+    }
+}
+
 template <int EPI>
 static bool launch_gemm(hipStream_t st, const uint16_t* A, const uint16_t* W, const float* bias, const uint16_t* resid,
                         uint16_t* C, int M, int N, int K, bool want_blocked = false)
 {
     // returns true iff C was written in the blocked layout (only the weight-stationary kernel can)
     if (launch_gemm_ws<EPI>(st, A, W, bias, resid, C, M, N, K, want_blocked)) return want_blocked;
+    // a query or a few short chunks: one memory round trip per GEMM instead of a walk over K (MI_GEMM_SKINNY=0: the general kernel)
+    static const bool skinny_off = getenv("MI_GEMM_SKINNY") && atoi(getenv("MI_GEMM_SKINNY")) == 0;
+    static const int skinny_rows = getenv("MI_GEMM_SKINNY_ROWS") ? atoi(getenv("MI_GEMM_SKINNY_ROWS")) : 384;
+    if (!skinny_off && M <= skinny_rows && N % 64 == 0) {
+        const unsigned gy = (unsigned)((M + 31) / 32);
+        if (K == 384) { gemm_skinny_kernel<EPI, 1><<<dim3((unsigned)(N / 64), gy), 256, 0, st>>>(A, W, bias, resid, C, M, N, K); return false; }
+        if (K == 1536) { gemm_skinny_kernel<EPI, 4><<<dim3((unsigned)(N / 16), gy), 256, 0, st>>>(A, W, bias, resid, C, M, N, K); return false; }
+    }
     const int n_tiles = N / GM_BN, m_tiles = (M + GM_BM - 1) / GM_BM;
     const unsigned grid = (unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles);
     // a grid that cannot put four workgroups on every CU takes the ring-of-four form (MI_GEMM_RING=0: never)

@@ -180,6 +180,28 @@ print("WORST", worst)
 """
 
 
+@pytest.mark.parametrize("B,L", [(1, 5), (1, 16), (1, 17), (1, 32), (2, 20), (1, 100), (4, 32), (3, 43), (1, 256), (3, 128)])
+def test_query_sized_calls_take_the_skinny_gemm(oracle_mod, B, L):
+    """embed_query (advanced_rag.py:296 embeds the query before every search): up to 384 tokens the four GEMMs of a layer
+    run as gemm_skinny_kernel (one round trip of W and x fragments into registers; K = 1536 split over the four waves of
+    a workgroup; 32 rows per workgroup row) -- one and two 16-row blocks, several row groups, row counts that are no
+    multiple of 16; test_minilm_dims_match_oracle keeps the general kernel covered (768 and more tokens).  Same bar."""
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import random_blob
+    cfg, ocfg = _cfgs(oracle_mod, 2000, 384, 6, 12, 1536, 512, 2, 1e-12, 1)
+    blob = random_blob(cfg, seed=11, init_range=0.05)
+    rng = np.random.default_rng(B * 977 + L)
+    ids = rng.integers(0, 2000, size=(B, L)).astype(np.int32)
+    mask = np.ones((B, L), dtype=np.int32)
+    for b in range(1, B):
+        mask[b, rng.integers(1, L + 1):] = 0
+    enc = Encoder(cfg, blob)
+    E = enc.encode_ids(ids, mask)
+    assert enc.stats()["latency_passes"] == 1
+    err = _cos_err(E, oracle_mod.encode(ocfg, blob, ids, mask))
+    assert np.all(err < TOL), err
+
+
 @pytest.mark.parametrize("env", [{"MI_FFN_FRONT": "0"}, {"MI_FFN_FUSED": "0"}, {"MI_FFN_FUSED": "0", "MI_GEMM_WS": "0"},
                                  {"MI_FFN_FUSED": "0", "MI_GEMM_LN": "0"},
                                  {"MI_FFN_FUSED": "0", "MI_GEMM_LN": "0", "MI_GEMM_RING": "0"},
