@@ -219,9 +219,10 @@ int  mi_encoder_encode_dev(mi_encoder* enc, int64_t B, int L, const int32_t* ids
  * (advanced_rag.py:295): n sequences as one flat token array; sequence i is
  * flat_ids[offsets[i] .. offsets[i+1]) (host int32 / int64 [n+1]); out_emb host fp32 [n][hidden]
  * in INPUT order.  The library does what sentence-transformers' encode loop does above the
- * boundary -- sort by length, cut into batches, pad each to its longest -- except that a batch is
- * cut by a token budget (64K tokens) instead of 32 rows, so bulk calls run the fused bulk
- * kernels whatever the length mix.  max_len > 0 truncates sequences (the tokenizer's
+ * boundary -- sort by length, cut into batches -- except that a batch is cut by a token budget
+ * (64K tokens) instead of 32 rows, so bulk calls run the fused bulk kernels whatever the length
+ * mix, and that the tokens of a batch are packed back to back instead of padded to the longest
+ * sequence: no padding token is computed.  max_len > 0 truncates sequences (the tokenizer's
  * max_seq_length, 256 for all-MiniLM-L6-v2); max_batch > 0 caps the rows per batch
  * (encode_kwargs["batch_size"] when the caller sets it).  An empty sequence yields a zero vector. */
 int  mi_encoder_encode_ragged(mi_encoder* enc, int64_t n, const int32_t* flat_ids, const int64_t* offsets,

@@ -106,7 +106,7 @@ __device__ __forceinline__ float wave_sum(float v)
 // One wave per token; lane holds columns lane, lane+64, ... (H <= 1024).
 template <int NCH>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ type_ids,
-        int ntypes, int64_t T, int L, int H, int vocab,
+        const int32_t* __restrict__ pos_ids, int ntypes, int64_t T, int L, int H, int vocab,
         const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ type_tab,
         const float* __restrict__ gamma, const float* __restrict__ beta, float eps, uint16_t* __restrict__ out)
 {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict
     int tt = type_ids ? type_ids[tok] : 0;
     if (tt < 0 || tt >= ntypes) tt = 0;
     const float* const type0 = type_tab + (int64_t)tt * H;
-    const int p = (int)(tok % L);
+    const int p = pos_ids ? pos_ids[tok] : (int)(tok % L);          // packed (unpadded) sequences bring their positions
     float x[NCH][8];
     float s = 0.0f;
 #pragma unroll
@@ -1595,8 +1595,18 @@ __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ 
 // in-register plus one cross-half exchange; P (bf16) feeds O^T = V^T P^T directly as the B
 // operand (the accumulator-as-operand k-permutation is matched by the V^T fragment reads).
 __global__ __launch_bounds__(256, 4) void attn_kernel(const uint16_t* __restrict__ qkv, const int32_t* __restrict__ mask,
-        uint16_t* __restrict__ ctx, int L, int Lp, int H, int qkv_blocked, int ctx_blocked)
+        const int32_t* __restrict__ seq_start, uint16_t* __restrict__ ctx, int L_in, int Lp_in, int H, int qkv_blocked, int ctx_blocked)
 {
+    // padded [B][L] tokens with a key mask, or packed sequences: tokens seq_start[b] .. seq_start[b + 1], no padding anywhere
+    // (L_in / Lp_in then only size the launch: the longest sequence of the pass)
+    int L = L_in, Lp = Lp_in;
+    int64_t tok0 = (int64_t)blockIdx.y * L_in;
+    if (seq_start) {
+        tok0 = seq_start[blockIdx.y];
+        L = seq_start[blockIdx.y + 1] - seq_start[blockIdx.y];
+        Lp = (L + 31) / 32 * 32;
+        if ((int)blockIdx.z * 256 >= L) return;              // whole workgroup: this sequence has no such query block
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // Ks [Lp][64 B] swizzled | Vs [Lp][64 B] | maskf [Lp]
     char* Ks = smem;
@@ -1608,10 +1618,9 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const uint16_t* __restrict
     const int hp = lane >> 5, col = lane & 31;
     const int head = blockIdx.x, b = blockIdx.y;
     const int H3 = 3 * H;
-    const uint16_t* base = qkv + (int64_t)b * L * H3 + head * 32;
+    const uint16_t* base = qkv + tok0 * H3 + head * 32;
     // blocked layouts ([tokens / 128][columns / 32][128][32], written by gemm_ws_kernel / read by
     // gemm_ln_kernel): the 32 columns of a head are one column block, 128 tokens of it one 8-KB block
-    const int64_t tok0 = (int64_t)b * L;
     const int nblk_q = H3 >> 5, nblk_c = H >> 5;
     auto qkv_at = [&](int key, int which, int c) -> const uint16_t* {     // which: 0 Q, 1 K, 2 V; c: 8-column chunk
         if (qkv_blocked) {
@@ -1632,7 +1641,7 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const uint16_t* __restrict
         *reinterpret_cast<uint4*>(Vs + key * 64 + c * 16) = vv;      // row-major: the transposed fragments come from ds_read_b64_tr_b16
     }
     for (int key = t; key < Lp; key += 256)
-        maskf[key] = (key < L && mask[(int64_t)b * L + key] != 0) ? 0.0f : -FLT_MAX;
+        maskf[key] = (key < L && (seq_start || mask[tok0 + key] != 0)) ? 0.0f : -FLT_MAX;
     __syncthreads();
 
     const int q0 = blockIdx.z * 256 + wave * 64;
@@ -1766,7 +1775,7 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const uint16_t* __restrict
 #define POOL_WAVES 16
 template <int NCH>
 __global__ __launch_bounds__(64 * POOL_WAVES) void pool_kernel(const uint16_t* __restrict__ hid, const int32_t* __restrict__ mask,
-        int L, int H, int normalize, float* __restrict__ out)
+        const int32_t* __restrict__ seq_start, int L_in, int H, int normalize, float* __restrict__ out)
 {
     __shared__ float part[POOL_WAVES][NCH * 512];
     __shared__ float red[POOL_WAVES];
@@ -1778,10 +1787,13 @@ __global__ __launch_bounds__(64 * POOL_WAVES) void pool_kernel(const uint16_t* _
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[c][e] = 0.0f;
     int cnt = 0;
+    // padded [B][L] rows with a mask, or packed sequences (rows seq_start[b] .. seq_start[b + 1], every token valid)
+    const int64_t tok0 = seq_start ? (int64_t)seq_start[b] : b * L_in;
+    const int L = seq_start ? seq_start[b + 1] - seq_start[b] : L_in;
     for (int i = wave; i < L; i += POOL_WAVES) {
-        if (mask[b * L + i] == 0) continue;      // wave-uniform
+        if (!seq_start && mask[tok0 + i] == 0) continue;      // wave-uniform
         ++cnt;
-        const uint16_t* row = hid + (b * L + i) * H;
+        const uint16_t* row = hid + (tok0 + i) * H;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int col = 8 * lane + 512 * c;
@@ -2273,12 +2285,16 @@ static int ensure_ws(mi_encoder* e, int64_t T, hipStream_t st)
 // types: token type ids or nullptr (all 0).  out_emb: pooled sentence embeddings [B][H], or nullptr;
 // out_logits: cross-encoder logits [B][nlabels], or nullptr.  ws_ext: caller-supplied workspace of ws_ext_bytes
 // (the allocation-free entry point), or nullptr: the encoder's own grow-only workspace.
+// One pass over B sequences.  Padded: ids / types / mask are [B][L].  Packed (seq_start != nullptr): ids and pos_ids hold the
+// T_packed tokens of the sequences back to back, seq_start[b] .. seq_start[b + 1] are sequence b's, L is the longest, mask
+// and types are unused -- no padding token is computed anywhere (mi_encoder_encode_ragged).
 static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids, const int32_t* types, const int32_t* mask,
-                              float* out_emb, float* out_logits, hipStream_t st, void* ws_ext, size_t ws_ext_bytes)
+                              float* out_emb, float* out_logits, hipStream_t st, void* ws_ext, size_t ws_ext_bytes,
+                              const int32_t* pos_ids = nullptr, const int32_t* seq_start = nullptr, int64_t T_packed = 0)
 {
     const mi_bert_config& c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size, NH = c.num_attention_heads;
-    const int64_t T = B * L;
+    const int64_t T = seq_start ? T_packed : B * L;
     MI_REQUIRE(T < ((int64_t)1 << 31) / 16, "encode: too many tokens in one call (%lld)", (long long)T);
     const size_t need = encoder_ws_need(c, T);
     void* wsp = nullptr;
@@ -2323,11 +2339,11 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     // MI_FFN2=0: the first form of the fused FFN (ffn_ln_kernel) instead of the K-split one (ffn2_kernel); read per call (A/B)
     const bool ffn2 = !(getenv("MI_FFN2") && atoi(getenv("MI_FFN2")) == 0);
     MI_HIP(hipEventRecord(e->ev0, st));
-    if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, types, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
-    else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, types, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
+    if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, types, pos_ids, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
+    else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, types, pos_ids, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     for (const LayerW& lw : e->layers) {
         const bool qkv_blocked = launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H, true);
-        attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, ctx, L, Lp, H, qkv_blocked ? 1 : 0, fused_ln ? 1 : 0);
+        attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, seq_start, ctx, L, Lp, H, qkv_blocked ? 1 : 0, fused_ln ? 1 : 0);
         if (fused_front && ffn2) {
             ffn2_kernel<true><<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T,
                                                                            ctx, lw.Wo_p, lw.bo, lw.g1, lw.b1);
@@ -2366,8 +2382,8 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
         }
     }
     if (out_emb) {
-        if (H <= 512) pool_kernel<1><<<(unsigned)B, 64 * POOL_WAVES, 0, st>>>(h, mask, L, H, c.normalize, out_emb);
-        else pool_kernel<2><<<(unsigned)B, 64 * POOL_WAVES, 0, st>>>(h, mask, L, H, c.normalize, out_emb);
+        if (H <= 512) pool_kernel<1><<<(unsigned)B, 64 * POOL_WAVES, 0, st>>>(h, mask, seq_start, L, H, c.normalize, out_emb);
+        else pool_kernel<2><<<(unsigned)B, 64 * POOL_WAVES, 0, st>>>(h, mask, seq_start, L, H, c.normalize, out_emb);
     }
     if (out_logits) {
         const float* hw = e->head;
@@ -2564,9 +2580,11 @@ extern "C" int mi_encoder_classify(mi_encoder* e, int64_t B, int L, const int32_
 
 // Ragged bulk embedding: n sequences as one flat token array + offsets (sequence i = flat_ids[offsets[i] ..
 // offsets[i + 1])), results in input order.  This is sentence-transformers' encode loop moved below the boundary:
-// sort by length (longest first), cut into passes, pad each pass to its longest sequence -- but a pass is cut by a
-// TOKEN budget (MI_ENC_PASS_TOKENS, 64K) instead of a fixed 32 rows, so bulk calls reach the fused per-tile kernels
-// whatever the length mix.  Passes are staged through two pinned blocks: the host packs pass i + 1 (and unpacks
+// sort by length (longest first), cut into passes by a TOKEN budget (MI_ENC_PASS_TOKENS, 64K) instead of a fixed 32 rows, so
+// bulk calls reach the fused per-tile kernels whatever the length mix -- and, where sentence-transformers pads a batch to its
+// longest sequence, the tokens of a pass are PACKED back to back: the GEMM / LayerNorm / FFN kernels work on token rows and
+// never see sequence boundaries, attention and pooling take the sequence starts, the embedding lookup takes the positions.
+// No padding token is computed (the padded form of a uniform 32..256 mix carried 8.9 % of them).  Passes are staged through two pinned blocks: the host packs pass i + 1 (and unpacks
 // pass i - 1) while the GPU runs pass i.
 extern "C" int mi_encoder_encode_ragged(mi_encoder* e, int64_t n, const int32_t* flat_ids, const int64_t* offsets,
                                         int max_len, int max_batch, float* out_emb)
@@ -2593,33 +2611,58 @@ extern "C" int mi_encoder_encode_ragged(mi_encoder* e, int64_t n, const int32_t*
     hipStream_t st = e->stream;
     const int64_t budget = encoder_pass_tokens();
     const int64_t bcap = (max_batch > 0 && max_batch < 4096) ? max_batch : 4096;          // rows per pass (bounds the pinned blocks)
-    struct Pass { int64_t first, B; int L; };
-    // cut the passes first: every buffer is then sized once, for the largest of them
+    // MI_ENC_VARLEN=0: pad every pass to its longest sequence (the round-2 start form) instead of packing the tokens
+    static const bool varlen = !(getenv("MI_ENC_VARLEN") && atoi(getenv("MI_ENC_VARLEN")) == 0);
+    struct Pass { int64_t first, B; int L; int64_t T; };
+    // cut the passes first: every buffer is then sized once, for the largest of them.  Packed: a pass takes sequences while
+    // their TRUE token count fits the budget; padded: B x longest.  An empty sequence is given one token (padded: masked;
+    // packed: its embedding is overwritten with zeros on the way out).
     std::vector<Pass> passes;
     size_t Tmax = 0, Bmax = 0;
+    // packed passes are balanced: ceil(total / budget) passes of about equal token counts, so the last one is no stub that
+    // would drop to the small-call kernels (a pass may exceed the budget by less than one sequence)
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; ++i) total += lens[(size_t)i] > 0 ? lens[(size_t)i] : 1;
+    const int64_t npass = (total + budget - 1) / budget;
+    const int64_t budget_eff = (total + npass - 1) / npass;
     for (int64_t next = 0; next < n;) {
         int L = lens[(size_t)order[(size_t)next]];
-        if (L < 1) L = 1;                                // an empty sequence: one padding token, all-masked -> zero vector
-        int64_t B = budget / L;
-        if (B < 1) B = 1;
-        if (B > bcap) B = bcap;
-        if (B > n - next) B = n - next;
-        passes.push_back({next, B, L});
-        if ((size_t)B * L > Tmax) Tmax = (size_t)B * L;
+        if (L < 1) L = 1;
+        int64_t B = 0, T = 0;
+        if (varlen) {
+            while (next + B < n && B < bcap) {
+                const int len = lens[(size_t)order[(size_t)(next + B)]] > 0 ? lens[(size_t)order[(size_t)(next + B)]] : 1;
+                if (B > 0 && T >= budget_eff) break;
+                T += len; ++B;
+            }
+        } else {
+            B = budget / L;
+            if (B < 1) B = 1;
+            if (B > bcap) B = bcap;
+            if (B > n - next) B = n - next;
+            T = B * L;
+        }
+        passes.push_back({next, B, L, T});
+        if ((size_t)T > Tmax) Tmax = (size_t)T;
         if ((size_t)B > Bmax) Bmax = (size_t)B;
         next += B;
     }
-    const size_t io_bytes = std::max(2 * Tmax * sizeof(int32_t), (size_t)1 << 20), out_bytes = std::max(Bmax * H * sizeof(float), (size_t)1 << 20);
-    MI_TRY(ensure_io(e, Tmax, Bmax * H * sizeof(float), st));
+    // staging planes: ids [Tmax] | mask or positions [Tmax] | sequence starts [Bmax + 1]
+    const size_t io_elems = 2 * Tmax + Bmax + 1;
+    const size_t io_bytes = std::max(io_elems * sizeof(int32_t), (size_t)1 << 20), out_bytes = std::max(Bmax * H * sizeof(float), (size_t)1 << 20);
+    MI_TRY(ensure_io(e, Tmax + Bmax / 3 + 1, Bmax * H * sizeof(float), st));
     MI_TRY(ensure_ws(e, (int64_t)Tmax, st));
     for (int s = 0; s < 2 && s < (int)passes.size(); ++s) { MI_TRY(e->pin_io[s].ensure(io_bytes)); MI_TRY(e->pin_out[s].ensure(out_bytes)); }
-    Pass inflight[2] = {{0, 0, 0}, {0, 0, 0}};
+    Pass inflight[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     auto unpack = [&](int s) -> int {                    // results of the pass staged in set s -> caller's rows
         if (inflight[s].B == 0) return MI_OK;
         MI_HIP(hipEventSynchronize(e->ev_pin[s]));
         const float* src = static_cast<const float*>(e->pin_out[s].p);
-        for (int64_t r = 0; r < inflight[s].B; ++r)
-            memcpy(out_emb + order[(size_t)(inflight[s].first + r)] * H, src + r * H, (size_t)H * sizeof(float));
+        for (int64_t r = 0; r < inflight[s].B; ++r) {
+            const int64_t i = order[(size_t)(inflight[s].first + r)];
+            if (lens[(size_t)i] == 0) memset(out_emb + i * H, 0, (size_t)H * sizeof(float));      // an empty sequence embeds to the zero vector
+            else memcpy(out_emb + i * H, src + r * H, (size_t)H * sizeof(float));
+        }
         inflight[s].B = 0;
         return MI_OK;
     };
@@ -2629,24 +2672,41 @@ extern "C" int mi_encoder_encode_ragged(mi_encoder* e, int64_t n, const int32_t*
         const int L = ps.L;
         const int64_t B = ps.B;
         MI_TRY(unpack(s));                               // set s is free once its previous pass has been read back
-        const size_t T = (size_t)B * L;
+        const size_t T = (size_t)ps.T;
         int32_t* pid = static_cast<int32_t*>(e->pin_io[s].p);
-        int32_t* pmask = pid + T;
-        for (int64_t r = 0; r < B; ++r) {
-            const int64_t i = order[(size_t)(ps.first + r)];
-            const int len = lens[(size_t)i];
-            memcpy(pid + r * L, flat_ids + offsets[i], (size_t)len * sizeof(int32_t));
-            for (int c = 0; c < len; ++c) pmask[r * L + c] = 1;
-            if (len < L) {
-                memset(pid + r * L + len, 0, (size_t)(L - len) * sizeof(int32_t));
-                memset(pmask + r * L + len, 0, (size_t)(L - len) * sizeof(int32_t));
-            }
-        }
+        int32_t* pmask = pid + T;                        // mask (padded) or positions (packed)
+        int32_t* pstart = pmask + T;
         int32_t* d_ids = e->d_io;
-        int32_t* d_mask = e->d_io + 2 * Tmax;
-        MI_HIP(hipMemcpyAsync(d_ids, pid, T * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        MI_HIP(hipMemcpyAsync(d_mask, pmask, T * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        MI_TRY(encode_pass_locked(e, B, L, d_ids, nullptr, d_mask, e->d_out, nullptr, st, nullptr, 0));
+        int32_t* d_mask = d_ids + T;
+        int32_t* d_start = d_mask + T;
+        if (varlen) {
+            size_t at = 0;
+            for (int64_t r = 0; r < B; ++r) {
+                const int64_t i = order[(size_t)(ps.first + r)];
+                const int len = lens[(size_t)i];
+                pstart[r] = (int32_t)at;
+                if (len == 0) { pid[at] = 0; pmask[at] = 0; at += 1; continue; }
+                memcpy(pid + at, flat_ids + offsets[i], (size_t)len * sizeof(int32_t));
+                for (int c = 0; c < len; ++c) pmask[at + c] = c;
+                at += (size_t)len;
+            }
+            pstart[B] = (int32_t)at;
+            MI_HIP(hipMemcpyAsync(d_ids, pid, (2 * T + (size_t)B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            MI_TRY(encode_pass_locked(e, B, L, d_ids, nullptr, nullptr, e->d_out, nullptr, st, nullptr, 0, d_mask, d_start, (int64_t)T));
+        } else {
+            for (int64_t r = 0; r < B; ++r) {
+                const int64_t i = order[(size_t)(ps.first + r)];
+                const int len = lens[(size_t)i];
+                memcpy(pid + r * L, flat_ids + offsets[i], (size_t)len * sizeof(int32_t));
+                for (int c = 0; c < len; ++c) pmask[r * L + c] = 1;
+                if (len < L) {
+                    memset(pid + r * L + len, 0, (size_t)(L - len) * sizeof(int32_t));
+                    memset(pmask + r * L + len, 0, (size_t)(L - len) * sizeof(int32_t));
+                }
+            }
+            MI_HIP(hipMemcpyAsync(d_ids, pid, 2 * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            MI_TRY(encode_pass_locked(e, B, L, d_ids, nullptr, d_mask, e->d_out, nullptr, st, nullptr, 0));
+        }
         MI_HIP(hipMemcpyAsync(e->pin_out[s].p, e->d_out, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, st));
         MI_HIP(hipEventRecord(e->ev_pin[s], st));
         inflight[s] = ps;
