@@ -138,3 +138,50 @@ def test_one_encoder_shared_by_eight_threads(oracle_mod):
     [x.start() for x in th]
     [x.join() for x in th]
     assert not errors, errors[:3]
+
+
+_PADDED_CHILD = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import oracle
+from rag_amd._capi import BertConfig
+from rag_amd.embeddings import Encoder
+from rag_amd.encoder_weights import random_blob
+vals = (500, 384, 2, 12, 1536, 256, 2, 1e-12, 1)
+cfg, ocfg = BertConfig(*vals), oracle.BertConfig(*vals)
+blob = random_blob(cfg, seed=9, init_range=0.05)
+rng = np.random.default_rng(2)
+lens = rng.integers(0, 70, size=40)
+off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+flat = rng.integers(0, 500, size=int(off[-1])).astype(np.int32)
+enc = Encoder(cfg, blob)
+E = enc.encode_ragged(flat, off)
+worst = 0.0
+for i in range(40):
+    if lens[i] == 0:
+        assert np.all(E[i] == 0)
+        continue
+    ids = flat[off[i]:off[i + 1]][None, :]
+    Eo = oracle.encode(ocfg, blob, ids, np.ones_like(ids))[0]
+    worst = max(worst, 1.0 - float((E[i] * Eo).sum() / (np.linalg.norm(E[i]) * np.linalg.norm(Eo))))
+print("TOKENS", enc.stats()["tokens"], "REAL", int(np.maximum(lens, 1).sum()), "WORST", worst)
+"""
+
+
+@pytest.mark.parametrize("varlen", ["0", "1"])
+def test_padded_and_packed_passes_in_child_processes(varlen):
+    """MI_ENC_VARLEN (read once per process): "0" pads a pass to its longest sequence, the default packs its tokens back to
+    back.  Both against the oracle, empty sequences included; the packed form computes exactly the real tokens."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e["MI_ENC_VARLEN"] = varlen
+    out = subprocess.run([sys.executable, "-c", _PADDED_CHILD % root], env=e, capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0, out.stderr[-2000:]
+    f = out.stdout.strip().split()
+    tokens, real, worst = int(f[1]), int(f[3]), float(f[5])
+    assert worst < TOL, worst
+    assert (tokens == real) if varlen == "1" else (tokens > real)
