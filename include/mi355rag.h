@@ -240,6 +240,12 @@ int  mi_encoder_classify(mi_encoder* enc, int64_t B, int L, const int32_t* ids, 
                          const int32_t* mask, float* out_logits);
 int  mi_encoder_classify_dev(mi_encoder* enc, int64_t B, int L, const int32_t* ids_dev, const int32_t* type_ids_dev,
                              const int32_t* mask_dev, float* out_logits_dev, void* stream);
+/* The same for n pairs of different lengths as one flat token array (sequence i = flat_ids[offsets[i] .. offsets[i+1]),
+ * token types alongside): passes are cut by the token budget and packed without padding, as in
+ * mi_encoder_encode_ragged; out_logits host fp32 [n][num_labels] in INPUT order.  Pairs are never truncated here
+ * (1 .. max_position_embeddings tokens each: the tokenizer above the boundary truncates and keeps the closing [SEP]). */
+int  mi_encoder_classify_ragged(mi_encoder* enc, int64_t n, const int32_t* flat_ids, const int32_t* flat_type_ids,
+                                const int64_t* offsets, int max_batch, float* out_logits);
 
 /* Counters since creation: out[0] sequences encoded, out[1] tokens processed (padding included),
  * out[2] passes that ran the bulk kernel family (fused per-tile kernels, >= 12,288 tokens),

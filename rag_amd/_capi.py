@@ -88,6 +88,7 @@ SYMBOLS = {
     "mi_encoder_set_head": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32]),
     "mi_encoder_classify": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "mi_encoder_classify_dev": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mi_encoder_classify_ragged": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _vp]),
     "mi_encoder_stats": (_i32, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "mi_encoder_last_time": (_i32, [_vp, ctypes.POINTER(ctypes.c_float)]),
 }

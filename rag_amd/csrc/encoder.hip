@@ -1877,14 +1877,14 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
 // BertPooler + classifier (modeling_bert.py BertPooler: tanh(W_p h[CLS] + b_p); BertForSequenceClassification:
 // logits = W_c pooled + b_c; dropout is the identity at inference).  One workgroup per sequence, fp32 throughout;
 // an output is one wave's dot product (lanes over the hidden columns, coalesced rows of W).
-__global__ __launch_bounds__(256) void cls_head_kernel(const uint16_t* __restrict__ hid, int L, int H,
+__global__ __launch_bounds__(256) void cls_head_kernel(const uint16_t* __restrict__ hid, const int32_t* __restrict__ seq_start, int L, int H,
         const float* __restrict__ Wp, const float* __restrict__ bp, const float* __restrict__ Wc, const float* __restrict__ bc,
         int nlabels, float* __restrict__ out)
 {
     __shared__ float x[1024], pooled[1024];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t b = blockIdx.x;
-    const uint16_t* row = hid + b * L * (int64_t)H;              // the [CLS] token is position 0
+    const uint16_t* row = hid + (seq_start ? (int64_t)seq_start[b] : b * L) * (int64_t)H;      // the [CLS] token is position 0
     for (int c = t; c < H; c += 256) x[c] = bf2f(row[c]);
     __syncthreads();
     for (int o = wave; o < H; o += 4) {
@@ -2388,7 +2388,7 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     if (out_logits) {
         const float* hw = e->head;
         const size_t HH = (size_t)H;
-        cls_head_kernel<<<(unsigned)B, 256, 0, st>>>(h, L, H, hw, hw + HH * HH, hw + HH * HH + HH, hw + HH * HH + HH + (size_t)e->nlabels * HH,
+        cls_head_kernel<<<(unsigned)B, 256, 0, st>>>(h, seq_start, L, H, hw, hw + HH * HH, hw + HH * HH + HH, hw + HH * HH + HH + (size_t)e->nlabels * HH,
                                                      e->nlabels, out_logits);
     }
     MI_HIP(hipEventRecord(e->ev1, st));
@@ -2586,33 +2586,42 @@ extern "C" int mi_encoder_classify(mi_encoder* e, int64_t B, int L, const int32_
 // never see sequence boundaries, attention and pooling take the sequence starts, the embedding lookup takes the positions.
 // No padding token is computed (the padded form of a uniform 32..256 mix carried 8.9 % of them).  Passes are staged through two pinned blocks: the host packs pass i + 1 (and unpacks
 // pass i - 1) while the GPU runs pass i.
-extern "C" int mi_encoder_encode_ragged(mi_encoder* e, int64_t n, const int32_t* flat_ids, const int64_t* offsets,
-                                        int max_len, int max_batch, float* out_emb)
+// `flat_types` != nullptr: cross-encoder pairs -- token types ride along, the result is the classification head's logits
+// ([n][num_labels]); sequences are never truncated or empty there (the tokenizer above the boundary owns truncation: it
+// must keep the closing [SEP]).
+static int ragged_run(mi_encoder* e, const char* who, int64_t n, const int32_t* flat_ids, const int32_t* flat_types,
+                      const int64_t* offsets, int max_len, int max_batch, float* out_emb)
 {
-    MI_REQUIRE(e && n >= 0, "mi_encoder_encode_ragged: bad argument");
-    if (n == 0) return MI_OK;
-    MI_REQUIRE(flat_ids && offsets && out_emb, "mi_encoder_encode_ragged: NULL buffer");
-    MI_REQUIRE(max_len >= 0 && max_batch >= 0, "mi_encoder_encode_ragged: max_len / max_batch must be >= 0 (0 = no limit)");
+    const bool logits = flat_types != nullptr;
     const int Lcap = (max_len > 0 && max_len < e->cfg.max_position_embeddings) ? max_len : e->cfg.max_position_embeddings;
-    const int H = e->cfg.hidden_size;
     std::vector<int32_t> lens((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
         const int64_t len = offsets[i + 1] - offsets[i];
-        MI_REQUIRE(offsets[i] >= 0 && len >= 0, "mi_encoder_encode_ragged: offsets must be non-decreasing (sequence %lld)", (long long)i);
+        MI_REQUIRE(offsets[i] >= 0 && len >= 0, "%s: offsets must be non-decreasing (sequence %lld)", who, (long long)i);
+        if (logits) {
+            MI_REQUIRE(len >= 1 && len <= e->cfg.max_position_embeddings, "%s: pair %lld has %lld tokens (1 .. %d allowed)", who,
+                       (long long)i, (long long)len, e->cfg.max_position_embeddings);
+            for (int64_t c = 0; c < len; ++c)
+                MI_REQUIRE(flat_types[offsets[i] + c] >= 0 && flat_types[offsets[i] + c] < e->cfg.type_vocab_size,
+                           "%s: token type %d outside [0,%d)", who, flat_types[offsets[i] + c], e->cfg.type_vocab_size);
+        }
         lens[(size_t)i] = (int32_t)(len < Lcap ? len : Lcap);               // truncation, as the tokenizer's max_length would
-        MI_TRY(check_ids("mi_encoder_encode_ragged", e, flat_ids + offsets[i], lens[(size_t)i]));
+        MI_TRY(check_ids(who, e, flat_ids + offsets[i], lens[(size_t)i]));
     }
     std::vector<int64_t> order((size_t)n);
     for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return lens[(size_t)a] > lens[(size_t)b]; });
 
     std::lock_guard<std::mutex> lk(e->mu);
+    if (logits && !e->head) { mi_set_error("%s: no classification head loaded (mi_encoder_set_head)", who); return MI_ERR_INVALID_ARG; }
+    const int H = logits ? e->nlabels : e->cfg.hidden_size;       // floats per result row
     DeviceGuard guard(e->device);
     hipStream_t st = e->stream;
     const int64_t budget = encoder_pass_tokens();
     const int64_t bcap = (max_batch > 0 && max_batch < 4096) ? max_batch : 4096;          // rows per pass (bounds the pinned blocks)
     // MI_ENC_VARLEN=0: pad every pass to its longest sequence (the round-2 start form) instead of packing the tokens
-    static const bool varlen = !(getenv("MI_ENC_VARLEN") && atoi(getenv("MI_ENC_VARLEN")) == 0);
+    static const bool varlen_env = !(getenv("MI_ENC_VARLEN") && atoi(getenv("MI_ENC_VARLEN")) == 0);
+    const bool varlen = varlen_env || logits;                       // (pairs are always packed)
     struct Pass { int64_t first, B; int L; int64_t T; };
     // cut the passes first: every buffer is then sized once, for the largest of them.  Packed: a pass takes sequences while
     // their TRUE token count fits the budget; padded: B x longest.  An empty sequence is given one token (padded: masked;
@@ -2647,10 +2656,10 @@ extern "C" int mi_encoder_encode_ragged(mi_encoder* e, int64_t n, const int32_t*
         if ((size_t)B > Bmax) Bmax = (size_t)B;
         next += B;
     }
-    // staging planes: ids [Tmax] | mask or positions [Tmax] | sequence starts [Bmax + 1]
-    const size_t io_elems = 2 * Tmax + Bmax + 1;
+    // staging planes: ids [T] | mask or positions [T] | token types [T] (pairs only) | sequence starts [B + 1]
+    const size_t io_elems = (logits ? 3 : 2) * Tmax + Bmax + 1;
     const size_t io_bytes = std::max(io_elems * sizeof(int32_t), (size_t)1 << 20), out_bytes = std::max(Bmax * H * sizeof(float), (size_t)1 << 20);
-    MI_TRY(ensure_io(e, Tmax + Bmax / 3 + 1, Bmax * H * sizeof(float), st));
+    MI_TRY(ensure_io(e, (io_elems + 2) / 3, Bmax * H * sizeof(float), st));
     MI_TRY(ensure_ws(e, (int64_t)Tmax, st));
     for (int s = 0; s < 2 && s < (int)passes.size(); ++s) { MI_TRY(e->pin_io[s].ensure(io_bytes)); MI_TRY(e->pin_out[s].ensure(out_bytes)); }
     Pass inflight[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -2675,10 +2684,12 @@ extern "C" int mi_encoder_encode_ragged(mi_encoder* e, int64_t n, const int32_t*
         const size_t T = (size_t)ps.T;
         int32_t* pid = static_cast<int32_t*>(e->pin_io[s].p);
         int32_t* pmask = pid + T;                        // mask (padded) or positions (packed)
-        int32_t* pstart = pmask + T;
+        int32_t* ptype = pmask + T;                      // pairs only
+        int32_t* pstart = logits ? ptype + T : ptype;
         int32_t* d_ids = e->d_io;
         int32_t* d_mask = d_ids + T;
-        int32_t* d_start = d_mask + T;
+        int32_t* d_type = d_mask + T;
+        int32_t* d_start = logits ? d_type + T : d_type;
         if (varlen) {
             size_t at = 0;
             for (int64_t r = 0; r < B; ++r) {
@@ -2687,12 +2698,14 @@ extern "C" int mi_encoder_encode_ragged(mi_encoder* e, int64_t n, const int32_t*
                 pstart[r] = (int32_t)at;
                 if (len == 0) { pid[at] = 0; pmask[at] = 0; at += 1; continue; }
                 memcpy(pid + at, flat_ids + offsets[i], (size_t)len * sizeof(int32_t));
+                if (logits) memcpy(ptype + at, flat_types + offsets[i], (size_t)len * sizeof(int32_t));
                 for (int c = 0; c < len; ++c) pmask[at + c] = c;
                 at += (size_t)len;
             }
             pstart[B] = (int32_t)at;
-            MI_HIP(hipMemcpyAsync(d_ids, pid, (2 * T + (size_t)B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-            MI_TRY(encode_pass_locked(e, B, L, d_ids, nullptr, nullptr, e->d_out, nullptr, st, nullptr, 0, d_mask, d_start, (int64_t)T));
+            MI_HIP(hipMemcpyAsync(d_ids, pid, ((logits ? 3 : 2) * T + (size_t)B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            MI_TRY(encode_pass_locked(e, B, L, d_ids, logits ? d_type : nullptr, nullptr, logits ? nullptr : e->d_out, logits ? e->d_out : nullptr,
+                                      st, nullptr, 0, d_mask, d_start, (int64_t)T));
         } else {
             for (int64_t r = 0; r < B; ++r) {
                 const int64_t i = order[(size_t)(ps.first + r)];
@@ -2716,6 +2729,27 @@ extern "C" int mi_encoder_encode_ragged(mi_encoder* e, int64_t n, const int32_t*
     MI_TRY(unpack(s_old));
     MI_TRY(unpack(s_old ^ 1));
     return MI_OK;
+}
+
+extern "C" int mi_encoder_encode_ragged(mi_encoder* e, int64_t n, const int32_t* flat_ids, const int64_t* offsets,
+                                        int max_len, int max_batch, float* out_emb)
+{
+    MI_REQUIRE(e && n >= 0, "mi_encoder_encode_ragged: bad argument");
+    if (n == 0) return MI_OK;
+    MI_REQUIRE(flat_ids && offsets && out_emb, "mi_encoder_encode_ragged: NULL buffer");
+    MI_REQUIRE(max_len >= 0 && max_batch >= 0, "mi_encoder_encode_ragged: max_len / max_batch must be >= 0 (0 = no limit)");
+    return ragged_run(e, "mi_encoder_encode_ragged", n, flat_ids, nullptr, offsets, max_len, max_batch, out_emb);
+}
+
+// Cross-encoder logits for n (query, passage) pairs of different lengths, packed like mi_encoder_encode_ragged's passes.
+extern "C" int mi_encoder_classify_ragged(mi_encoder* e, int64_t n, const int32_t* flat_ids, const int32_t* flat_type_ids,
+                                          const int64_t* offsets, int max_batch, float* out_logits)
+{
+    MI_REQUIRE(e && n >= 0, "mi_encoder_classify_ragged: bad argument");
+    if (n == 0) return MI_OK;
+    MI_REQUIRE(flat_ids && flat_type_ids && offsets && out_logits, "mi_encoder_classify_ragged: NULL buffer");
+    MI_REQUIRE(max_batch >= 0, "mi_encoder_classify_ragged: max_batch must be >= 0 (0 = no limit)");
+    return ragged_run(e, "mi_encoder_classify_ragged", n, flat_ids, flat_type_ids, offsets, 0, max_batch, out_logits);
 }
 
 extern "C" int mi_encoder_stats(const mi_encoder* enc, int64_t out[4])

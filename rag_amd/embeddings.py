@@ -130,6 +130,24 @@ class Encoder:
                                                   mask.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
+    def classify_ragged(self, flat_ids: np.ndarray, flat_type_ids: np.ndarray, offsets: np.ndarray, max_batch: int = 0) -> np.ndarray:
+        """Cross-encoder logits [n][num_labels] for n pairs of different lengths (CSR: flat token ids and token types,
+        offsets [n + 1]); passes are packed without padding inside the library (mi_encoder_classify_ragged)."""
+        flat_ids = np.ascontiguousarray(flat_ids, dtype=np.int32)
+        flat_type_ids = np.ascontiguousarray(flat_type_ids, dtype=np.int32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if flat_ids.shape != flat_type_ids.shape or flat_ids.ndim != 1 or offsets.ndim != 1 or offsets.size < 1:
+            raise ValueError("flat_ids / flat_type_ids must be 1-d arrays of one shape, offsets [n + 1]")
+        if int(offsets[-1]) > flat_ids.size:
+            raise ValueError("offsets reach beyond flat_ids")
+        n = offsets.size - 1
+        out = np.empty((n, getattr(self, "num_labels", 1)), dtype=np.float32)
+        _capi.check(self._lib.mi_encoder_classify_ragged(self._h, n, flat_ids.ctypes.data_as(ctypes.c_void_p),
+                                                         flat_type_ids.ctypes.data_as(ctypes.c_void_p),
+                                                         offsets.ctypes.data_as(ctypes.c_void_p), int(max_batch),
+                                                         out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def stats(self) -> dict:
         out = (ctypes.c_int64 * 4)()
         _capi.check(self._lib.mi_encoder_stats(self._h, out))

@@ -178,6 +178,21 @@ def rerank_pairs(query: str, documents: Sequence[Document], tokenizer: Any, max_
     return ids, types, mask
 
 
+def rerank_pairs_csr(pairs: Sequence[Sequence[str]], tokenizer: Any, max_length: int = 512):
+    """(query, passage) pairs -> one flat int32 token array, its token types and offsets [n + 1] (no padding): the input
+    of mi_encoder_classify_ragged.  Truncation to max_length is the tokenizer's (it keeps the closing [SEP]); a
+    tokenizer without truncation configured is cut here as rerank_pairs does."""
+    import numpy as np
+    ids, types, offsets = [], [], [0]
+    for q, passage in pairs:
+        e = tokenizer.encode(q, passage)
+        m = min(len(e.ids), max_length)
+        ids.extend(e.ids[:m])
+        types.extend(e.type_ids[:m])
+        offsets.append(offsets[-1] + m)
+    return np.asarray(ids, dtype=np.int32), np.asarray(types, dtype=np.int32), np.asarray(offsets, dtype=np.int64)
+
+
 class CrossEncoderReranker:
     """Scores (query, passage) pairs with a BERT cross-encoder on the MI355X and re-orders the candidates: the
     consumer of BASELINE config 5's top-100 lists (README.md:27 and requirements.txt:24 name a reranker; the
@@ -202,15 +217,21 @@ class CrossEncoderReranker:
         import numpy as np
         if not pairs:
             return np.zeros((0,), dtype=np.float32)
-        docs = [Document(page_content=p[1]) for p in pairs]
-        queries = {p[0] for p in pairs}
-        if len(queries) == 1:
-            ids, types, mask = rerank_pairs(pairs[0][0], docs, self.tokenizer, self.max_length)
+        # pairs of different lengths go down as one flat token array: the library packs its passes without padding
+        # (mi_encoder_classify_ragged).  An encoder without that entry point (a test double) gets the padded batch.
+        if hasattr(self.encoder, "classify_ragged"):
+            flat_ids, flat_types, offsets = rerank_pairs_csr(pairs, self.tokenizer, self.max_length)
+            logits = self.encoder.classify_ragged(flat_ids, flat_types, offsets)
         else:
-            parts = [rerank_pairs(p[0], [d], self.tokenizer, self.max_length) for p, d in zip(pairs, docs)]
-            L = max(a[0].shape[1] for a in parts)
-            ids, types, mask = (np.concatenate([np.pad(a[j], ((0, 0), (0, L - a[j].shape[1]))) for a in parts]) for j in range(3))
-        logits = self.encoder.classify(ids, types, mask)
+            docs = [Document(page_content=p[1]) for p in pairs]
+            queries = {p[0] for p in pairs}
+            if len(queries) == 1:
+                ids, types, mask = rerank_pairs(pairs[0][0], docs, self.tokenizer, self.max_length)
+            else:
+                parts = [rerank_pairs(p[0], [d], self.tokenizer, self.max_length) for p, d in zip(pairs, docs)]
+                L = max(a[0].shape[1] for a in parts)
+                ids, types, mask = (np.concatenate([np.pad(a[j], ((0, 0), (0, L - a[j].shape[1]))) for a in parts]) for j in range(3))
+            logits = self.encoder.classify(ids, types, mask)
         s = logits[:, 0] if logits.shape[1] == 1 else logits
         if self.activation == "sigmoid":
             s = 1.0 / (1.0 + np.exp(-s))

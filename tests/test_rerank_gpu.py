@@ -93,6 +93,53 @@ def test_minilm_cross_encoder_matches_oracle(oracle_mod, kernel_family):
         Encoder(cfg, blob).classify(ids, types, mask)    # no head loaded
 
 
+def test_packed_pairs_match_padded_and_oracle(oracle_mod, kernel_family):
+    """mi_encoder_classify_ragged: pairs of different lengths as one flat token array, packed passes (no padding token is
+    computed), logits in input order -- against the padded entry point on the same pairs and against the oracle; bad
+    inputs fail loudly."""
+    from rag_amd import MI355Error
+    from rag_amd._capi import BertConfig
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import random_blob, random_head
+    vals = (2000, 384, 3, 12, 1536, 512, 2, 1e-12, 0)
+    cfg, ocfg = BertConfig(*vals), oracle_mod.BertConfig(*vals)
+    blob = random_blob(cfg, seed=16, init_range=0.05)
+    head = random_head(cfg, num_labels=2, seed=17, init_range=0.1)
+    rng = np.random.default_rng(12)
+    n, L = 37, 96
+    lens = rng.integers(5, L + 1, size=n)
+    ids = np.zeros((n, L), dtype=np.int32)
+    types = np.zeros((n, L), dtype=np.int32)
+    mask = np.zeros((n, L), dtype=np.int32)
+    for b in range(n):
+        ids[b, :lens[b]] = rng.integers(4, 2000, size=lens[b])
+        types[b, lens[b] // 3:lens[b]] = 1
+        mask[b, :lens[b]] = 1
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat_ids = np.concatenate([ids[b, :lens[b]] for b in range(n)])
+    flat_types = np.concatenate([types[b, :lens[b]] for b in range(n)])
+    enc = Encoder(cfg, blob)
+    enc.set_head(*head)
+    t0 = enc.stats()["tokens"]
+    got = enc.classify_ragged(flat_ids, flat_types, off)
+    assert enc.stats()["tokens"] - t0 == int(lens.sum())           # exactly the real tokens
+    tol = _logit_tol(head[0], head[2])
+    padded = enc.classify(ids, types, mask)
+    assert got.shape == (n, 2) and np.abs(got - padded).max() < tol
+    sel = list(range(0, n, 4))
+    want = oracle_mod.classify(ocfg, blob, head, ids[sel], types[sel], mask[sel])
+    assert np.abs(got[sel] - want).max() < tol
+    got7 = enc.classify_ragged(flat_ids, flat_types, off, max_batch=7)                  # several passes
+    assert np.abs(got7 - got).max() < tol
+    with pytest.raises(MI355Error):
+        enc.classify_ragged(flat_ids, flat_types + 2, off)         # token type outside [0, type_vocab_size)
+    bad = off.copy(); bad[3] = bad[2]                              # an empty pair
+    with pytest.raises(MI355Error):
+        enc.classify_ragged(flat_ids, flat_types, bad)
+    with pytest.raises(MI355Error):
+        Encoder(cfg, blob).classify_ragged(flat_ids, flat_types, off)                   # no head loaded
+
+
 def test_top100_feeds_the_rerank_batch(tmp_path, oracle_mod):
     """BASELINE config 5's shape end to end: 768-d bf16 index -> top-100 (MFMA scan, K' = 128 lists) -> (query, passage)
     pairs -> cross-encoder scores -> re-ordered candidates.  The retrieval is bit-exact vs the oracle; the scores are
