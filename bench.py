@@ -64,7 +64,8 @@ def bench_embed(args, dev, rank, world, barrier):
       value     ids and mask resident in HBM, all-ones mask (the peak)
       via_api   the same chunks from HOST token ids to HOST embeddings through mi_encoder_encode_ragged, the call
                 MI355Embeddings.embed_tokenized / embed_documents_array makes (FAISS.from_documents, advanced_rag.py:295)
-      ragged    lengths uniform in [32, 256] through the same call (the realistic mix)"""
+      ragged    lengths uniform in [32, 256] through the same call (the realistic mix)
+    plus `rerank`: cross-encoder pairs/s through mi_encoder_classify_ragged (BASELINE config 5's consumer)."""
     from rag_amd.embeddings import Encoder
     from rag_amd.encoder_weights import minilm_l6_config, random_blob
     cfg = minilm_l6_config()
@@ -139,6 +140,23 @@ def bench_embed(args, dev, rank, world, barrier):
                      "padding_overhead": round((st1["tokens"] - st0["tokens"]) / real_tok - 1.0, 4),
                      "bulk_passes": st1["bulk_passes"] - st0["bulk_passes"], "latency_passes": st1["latency_passes"] - st0["latency_passes"],
                      "roofline": roof(flops(lens) * args.embed_steps, el_r)}
+
+    # ---- BASELINE config 5's consumer: top-100 lists -> cross-encoder scores (ms-marco-MiniLM-L-6 dimensions, seeded random
+    # weights): 32 queries x 100 (query, passage) pairs of 64..384 tokens through mi_encoder_classify_ragged (host in, host out)
+    if B >= 256:
+        from rag_amd.encoder_weights import random_head
+        enc.set_head(*random_head(cfg, num_labels=1, seed=5, init_range=0.1))
+        prng = np.random.default_rng(99 + rank)
+        plen = prng.integers(64, 385, size=3200)
+        poff = np.concatenate([[0], np.cumsum(plen)]).astype(np.int64)
+        pflat = prng.integers(1000, 30000, size=int(poff[-1])).astype(np.int32)
+        ptype = np.concatenate([(np.arange(m) >= 16).astype(np.int32) for m in plen])
+        enc.classify_ragged(pflat[:poff[100]], ptype[:poff[100]], poff[:101])
+        el_p, _ = timed(lambda: enc.classify_ragged(pflat, ptype, poff), args.embed_steps)
+        res["rerank"] = {"value": round(3200 * args.embed_steps * world / el_p, 1), "unit": "pairs/s",
+                         "pairs": "32 queries x 100 candidates, 64..384 tokens per pair (mean %.0f), packed passes" % plen.mean(),
+                         "tokens_per_s": round(float(plen.sum()) * args.embed_steps * world / el_p, 1),
+                         "roofline": roof(flops(plen) * args.embed_steps, el_p)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
