@@ -1877,30 +1877,53 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__
 // BertPooler + classifier (modeling_bert.py BertPooler: tanh(W_p h[CLS] + b_p); BertForSequenceClassification:
 // logits = W_c pooled + b_c; dropout is the identity at inference).  One workgroup per sequence, fp32 throughout;
 // an output is one wave's dot product (lanes over the hidden columns, coalesced rows of W).
-__global__ __launch_bounds__(256) void cls_head_kernel(const uint16_t* __restrict__ hid, const int32_t* __restrict__ seq_start, int L, int H,
-        const float* __restrict__ Wp, const float* __restrict__ bp, const float* __restrict__ Wc, const float* __restrict__ bc,
-        int nlabels, float* __restrict__ out)
+#define CLS_PB 4                                 // pairs per workgroup: the pooler matrix is read once per four pairs
+// One thread per pooler output; WpT is the pooler matrix transposed at load ([in][out]) so a wave reads 64 consecutive
+// outputs of one input column, and the four [CLS] rows sit in LDS as [in][CLS_PB] for one broadcast b128 read per column.
+__global__ __launch_bounds__(1024) void cls_head_kernel(const uint16_t* __restrict__ hid, const int32_t* __restrict__ seq_start, int L, int H,
+        const float* __restrict__ WpT, const float* __restrict__ bp, const float* __restrict__ Wc, const float* __restrict__ bc,
+        int nlabels, int64_t B, float* __restrict__ out)
 {
-    __shared__ float x[1024], pooled[1024];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int64_t b = blockIdx.x;
-    const uint16_t* row = hid + (seq_start ? (int64_t)seq_start[b] : b * L) * (int64_t)H;      // the [CLS] token is position 0
-    for (int c = t; c < H; c += 256) x[c] = bf2f(row[c]);
-    __syncthreads();
-    for (int o = wave; o < H; o += 4) {
-        float s = 0.0f;
-        for (int c = lane; c < H; c += 64) s += Wp[(int64_t)o * H + c] * x[c];
-        s = wave_sum(s);
-        if (lane == 0) pooled[o] = tanhf(s + bp[o]);
+    extern __shared__ float cls_smem[];              // x [H][CLS_PB] | pooled [CLS_PB][H]
+    float* x = cls_smem;
+    float* pooled = cls_smem + CLS_PB * H;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * CLS_PB;
+    const int np = (int)((B - b0 < CLS_PB) ? B - b0 : CLS_PB);
+    for (int i = t; i < CLS_PB * H; i += blockDim.x) {
+        const int p = i / H, c = i - p * H;
+        float v = 0.0f;
+        if (p < np) {
+            const int64_t b = b0 + p;
+            v = bf2f(hid[(seq_start ? (int64_t)seq_start[b] : b * L) * (int64_t)H + c]);      // the [CLS] token is position 0
+        }
+        x[c * CLS_PB + p] = v;
     }
     __syncthreads();
-    for (int j = wave; j < nlabels; j += 4) {
+    if (t < H) {
+        float s[CLS_PB];
+#pragma unroll
+        for (int p = 0; p < CLS_PB; ++p) s[p] = 0.0f;
+#pragma unroll 8
+        for (int c = 0; c < H; ++c) {
+            const float w = WpT[(int64_t)c * H + t];
+            const float4 xv = *reinterpret_cast<const float4*>(x + c * CLS_PB);
+            s[0] += w * xv.x; s[1] += w * xv.y; s[2] += w * xv.z; s[3] += w * xv.w;
+        }
+        const float bo = bp[t];
+#pragma unroll
+        for (int p = 0; p < CLS_PB; ++p) pooled[p * H + t] = tanhf(s[p] + bo);
+    }
+    __syncthreads();
+    for (int i = wave; i < np * nlabels; i += nw) {
+        const int p = i / nlabels, j = i - p * nlabels;
         float s = 0.0f;
-        for (int c = lane; c < H; c += 64) s += Wc[(int64_t)j * H + c] * pooled[c];
+        for (int c = lane; c < H; c += 64) s += Wc[(int64_t)j * H + c] * pooled[p * H + c];
         s = wave_sum(s);
-        if (lane == 0) out[b * nlabels + j] = s + bc[j];
+        if (lane == 0) out[(b0 + p) * nlabels + j] = s + bc[j];
     }
 }
+static_assert(CLS_PB == 4, "cls_head_kernel reads the four [CLS] values of a column as one float4");
 
 // ================================================================ host side
 // Activation workspace of the allocation-free entry point (mi_encoder_encode_dev_noalloc): callers that cannot
@@ -2112,7 +2135,9 @@ extern "C" int mi_encoder_set_head(mi_encoder* e, const float* pooler_w, const f
     if (e->head) { (void)hipFree(e->head); e->head = nullptr; e->nlabels = 0; }
     MI_HIP(hipMalloc((void**)&e->head, n * sizeof(float)));
     float* d = e->head;
-    MI_HIP(hipMemcpyAsync(d, pooler_w, H * H * 4, hipMemcpyHostToDevice, e->stream)); d += H * H;
+    std::vector<float> wT(H * H);                    // [in][out]: cls_head_kernel's threads own outputs
+    for (size_t o = 0; o < H; ++o) for (size_t c = 0; c < H; ++c) wT[c * H + o] = pooler_w[o * H + c];
+    MI_HIP(hipMemcpyAsync(d, wT.data(), H * H * 4, hipMemcpyHostToDevice, e->stream)); d += H * H;
     MI_HIP(hipMemcpyAsync(d, pooler_b, H * 4, hipMemcpyHostToDevice, e->stream)); d += H;
     MI_HIP(hipMemcpyAsync(d, cls_w, (size_t)num_labels * H * 4, hipMemcpyHostToDevice, e->stream)); d += (size_t)num_labels * H;
     MI_HIP(hipMemcpyAsync(d, cls_b, (size_t)num_labels * 4, hipMemcpyHostToDevice, e->stream));
@@ -2388,8 +2413,8 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     if (out_logits) {
         const float* hw = e->head;
         const size_t HH = (size_t)H;
-        cls_head_kernel<<<(unsigned)B, 256, 0, st>>>(h, seq_start, L, H, hw, hw + HH * HH, hw + HH * HH + HH, hw + HH * HH + HH + (size_t)e->nlabels * HH,
-                                                     e->nlabels, out_logits);
+        cls_head_kernel<<<(unsigned)((B + CLS_PB - 1) / CLS_PB), (unsigned)((H + 63) / 64 * 64), 2 * CLS_PB * HH * sizeof(float), st>>>(
+            h, seq_start, L, H, hw, hw + HH * HH, hw + HH * HH + HH, hw + HH * HH + HH + (size_t)e->nlabels * HH, e->nlabels, B, out_logits);
     }
     MI_HIP(hipEventRecord(e->ev1, st));
     MI_HIP(hipGetLastError());
