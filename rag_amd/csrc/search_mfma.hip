@@ -66,8 +66,16 @@ __host__ __device__ constexpr int mf_cap(int kp) { return 2 * kp + 32; }
 // d = 768: the 32x32x16 (HBM-bound) variant keeps 4 waves x 32 queries, one per SIMD with the 512-register budget;
 // the 16x16x32 (MFMA-bound) variant runs 8 waves x 16 queries, two per SIMD: a wave alone on its SIMD has nothing
 // to hide its barriers, DMA issue and LDS latency behind (0.84 PFLOP/s at 5M x 768 x 10k in round 1).
-__host__ __device__ constexpr int mf_waves(int nkb, bool m16) { return (nkb <= 3 || m16) ? 8 : 4; }
-__host__ __device__ constexpr int mf_qb(int nkb, bool m16) { return (nkb > 3 && m16) ? 1 : 2; }
+// At 16 queries per wave every 1-KB fragment read feeds ONE 16-cycle MFMA: four SIMDs then ask the LDS for 256 B/clk,
+// all it has -- the variant is LDS-bound as much as MFMA-bound.  MF_768_QB = 2 / 3 build the 16x16x32 variant with
+// four waves x 32 / 48 queries instead (half / a third of the reads; 288 fragment registers spill at 48): measured
+// at 20M x 768 x 10k on one device, k = 10 / 100: 1,053 / 1,028 (8 x 16), 1,077 / 991 (4 x 32), 968 / 892 TFLOP/s
+// (4 x 48) -- what the reads give back, a wave alone on its SIMD loses again.
+#ifndef MF_768_QB
+#define MF_768_QB 1
+#endif
+__host__ __device__ constexpr int mf_waves(int nkb, bool m16) { return (nkb <= 3 || (m16 && MF_768_QB == 1)) ? 8 : 4; }
+__host__ __device__ constexpr int mf_qb(int nkb, bool m16) { return (nkb > 3 && m16) ? MF_768_QB : 2; }
 __host__ __device__ constexpr int mf_qtile(int nkb, bool m16) { return 16 * mf_qb(nkb, m16) * mf_waves(nkb, m16); }
 
 // Four A fragments (rows 32 m + col, m = 0..3) of one k-step; completion is the caller's
@@ -262,10 +270,10 @@ __global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
     // 545 / 547 ms, fabric reads 194 / 200 / 257 / 489 / 1267 GB, clock under load 2.0 vs 1.93 GHz.
     constexpr uint32_t MF_MAX_LEAD = 8, MF_COHORT = 512;
     // unit u = (tile, kb) lives in ring buffer u & (MF_NST - 1); its tile's xx in xx buffer tile & 3
-    auto issue_unit = [&](int tile, int kb, int buf) __attribute__((always_inline)) {
+    auto issue_extras = [&](int tile, int kb) __attribute__((always_inline)) {
         if (kb == 0) {
             const unsigned l4 = lane_x4();
-            dma4_saddr_sc1(gsrc_u, l4 & 124u, lds_base + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256);
+            dma4_saddr_sc1(gsrc_u, l4 & (QW > 32 ? 252u : 124u), lds_base + MF_GT_OFF + ((tile & (MF_XXB - 1)) * 8 + wave) * 256);
             if constexpr (M16) {
                 if (wave == 0) dma4_saddr_sc1(prog, l4, lds_base + MF_PG_OFF + (tile & (MF_XXB - 1)) * 256);
             }
@@ -279,6 +287,10 @@ __global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
                                lds_base + MF_XX_OFF + (tile & (MF_XXB - 1)) * (MF_TILE_R * 4) + half * 256);
             }
         }
+    };
+    // pieces [I0, I0 + NI) of this wave's share of a unit
+    auto issue_pieces = [&](int tile, int kb, int buf, auto I0c, auto NIc) __attribute__((always_inline)) {
+        constexpr int I0 = decltype(I0c)::value, NI = decltype(NIc)::value;
         const char* const ub = ub0 + ((int64_t)tile * MF_TILE_R * pitch_bytes + kb * 256);      // wave-uniform
         unsigned voff0 = voff_reg;
         if constexpr (VOFF_INLINE) {
@@ -286,9 +298,13 @@ __global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
             voff0 = lrv * (unsigned)pitch_bytes + ((ltv ^ lrv) << 4);
         }
 #pragma unroll
-        for (int i = 0; i < PPW; ++i)
+        for (int i = I0; i < I0 + NI; ++i)
             dma16_saddr(ub + (int64_t)i * 4 * pitch_bytes, voff0 ^ ((unsigned)(i & 3) << 6),
                         lds_base + buf * MF_STAGE_BYTES + (wave * PPW + i) * 1024);
+    };
+    auto issue_unit = [&](int tile, int kb, int buf) __attribute__((always_inline)) {
+        issue_extras(tile, kb);
+        issue_pieces(tile, kb, buf, IC<0>{}, IC<PPW>{});
     };
     auto issue_linear = [&](int u) __attribute__((always_inline)) {                      // u < nunits
         issue_unit(u / NKB, u % NKB, u & (MF_NST - 1));
@@ -301,9 +317,10 @@ __global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
     float thr = (qglob < nq) ? -__builtin_inff() : __builtin_inff();
     int cnt = 0;
     uint64_t* const list = lists + ((int64_t)slice * nq_pad + qglob) * CAP;
-    float thr2[2] = {(qbase + l15 < nq) ? -__builtin_inff() : __builtin_inff(),       // 16x16x32: the lane's QB queries
-                     (QB > 1 && qbase + 16 + l15 < nq) ? -__builtin_inff() : __builtin_inff()};
-    int cnt2[2] = {0, 0};
+    float thr2[QB];                                                                   // 16x16x32: the lane's QB queries
+    int cnt2[QB];
+#pragma unroll
+    for (int cb = 0; cb < QB; ++cb) { thr2[cb] = (qbase + 16 * cb + l15 < nq) ? -__builtin_inff() : __builtin_inff(); cnt2[cb] = 0; }
 
     f32x16 acc[M16 ? 1 : 4];
     f32x4 acc16[M16 ? 8 : 1][QB];                                 // [16-row block][16-query block]
@@ -348,6 +365,10 @@ __global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
 #define MF_LEAD_768 10
 #endif
     constexpr int MF_LEAD = (NKB >= 6) ? MF_LEAD_768 : 25;
+#ifndef MF_ASYM_DMA
+#define MF_ASYM_DMA 1
+#endif
+    constexpr bool MF_ASYM = (MF_ASYM_DMA != 0) && WAVES == 8;
     constexpr int MF_PRO = M16 ? (MF_LEAD >= 20 ? 3 : 2) : MF_PD;
 #pragma unroll
     for (int u0 = 0; u0 < MF_PRO; ++u0)
@@ -545,7 +566,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
             // common case first, as one wide max tree and ONE branch per tile (eight dependent
             // max -> compare -> branch rounds cost ~90 cycles each)
             {
-                float m[2];
+                float m[QB];
 #pragma unroll
                 for (int cb = 0; cb < QB; ++cb) {
                     float m4[4];
@@ -558,7 +579,8 @@ __global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
                     m[cb] = __builtin_fmaxf(__builtin_fmaxf(m4[0], m4[1]), __builtin_fmaxf(m4[2], m4[3]));
                 }
                 bool any = m[0] > thr2[0];
-                if constexpr (QB > 1) any = any || (m[1] > thr2[1]);
+#pragma unroll
+                for (int cb = 1; cb < QB; ++cb) any = any || (m[cb] > thr2[cb]);
                 if (__builtin_amdgcn_ballot_w64(any) == 0) return;
             }
             const uint32_t rowbase = (uint32_t)(row_begin + (int64_t)tile * MF_TILE_R) + 4u * (uint32_t)g4;
@@ -697,6 +719,28 @@ __global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
                 if constexpr (kb == NKB - 1) { if (active) refresh_thr(tile); }
                 auto mid = [&]() __attribute__((always_inline)) {
                     stamp(1);
+                    if constexpr (MF_LEAD == 10 && MF_ASYM) {
+                        // The two waves of a SIMD (w and w + 4) issue their pieces of unit u + 2 on opposite sides of the
+                        // barrier: the younger one BEFORE it (behind its MFMAs), the older one right behind it.  Issued by both
+                        // at the same point the ~500 cycles of LDS-DMA issue leave the matrix pipe idle; this way each wave's
+                        // issue runs under the other's MFMAs.  The buffer of unit u + 2 held unit u - 2, which everyone left
+                        // before the barrier of unit u - 1.
+                        if (wave >= 4) {
+                            if (u + 2 < nunits) {
+                                issue_unit(tile + (kb + 2) / NKB, (kb + 2) % NKB, (u + 2) & (MF_NST - 1));
+                                wait_vm<PPW + (g2 ? 1 : 0)>();
+                            } else {
+                                wait_vm<0>();
+                            }
+                        } else {
+                            wait_vm<0>();
+                        }
+                        stamp(3);
+                        __builtin_amdgcn_s_barrier();
+                        if (wave < 4 && u + 2 < nunits) issue_unit(tile + (kb + 2) / NKB, (kb + 2) % NKB, (u + 2) & (MF_NST - 1));
+                        stamp(4);
+                        return;
+                    }
                     if (MF_LEAD != 10 && u + 2 < nunits) {
                         if (wave == 0) wait_vm<PPW + (g2 ? (L2 ? 4 : 2) : 0)>(); else wait_vm<PPW + (g2 ? 1 : 0)>();
                     } else {
@@ -1038,8 +1082,18 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
 {
     const int nkb = pick_nkb(d_pad), kp = pick_kp(k);
     if (!nkb || !kp || n < MF_MIN_ROWS || n >= ((int64_t)1 << 32) || k > MF_SORT_MAX / 2) return MI_ERR_UNSUPPORTED;
-    const int qtile = mf_qtile(nkb, false);                       // the same for both kernel variants of a dimension
-    static_assert(mf_qtile(6, false) == mf_qtile(6, true) && mf_qtile(3, false) == mf_qtile(3, true) && mf_qtile(1, false) == mf_qtile(1, true), "query tile");
+    // Up to 128 queries (four active waves, one per SIMD) the scan is HBM-bound: deep prefetch, 32x32x16.  Beyond,
+    // both waves of every SIMD carry MFMAs and the variant with the mid-unit barrier wins, also where the slice is
+    // still read by one or two query tiles only (100M x 384, one device: Q = 256 20.7 -> 18.9 ms, Q = 512
+    // 36.5 -> 33.3 ms, Q = 128 13.9 vs 13.85 ms; profiles/r02_midq_variants.jsonl)
+    plan->pd = (nq <= 128) ? 3 : 2;
+    if (const char* e = getenv("MI_MFMA_PD")) { const int v = atoi(e); if (v == 2 || v == 3) plan->pd = v; }
+    // MFMA shape: 16x16x32 in the MFMA-bound variant (+8.6 % at 100M x 384 on one device: same
+    // cycles, higher sustained clock); MI_MFMA_M16=0 selects 32x32x16 for A/B runs
+    plan->m16 = (plan->pd == 2) ? 1 : 0;
+    if (const char* e = getenv("MI_MFMA_M16")) plan->m16 = (atoi(e) != 0 && plan->pd == 2) ? 1 : 0;
+    const int qtile = mf_qtile(nkb, plan->m16 != 0);              // d = 768: the two variants tile the queries differently
+    static_assert(mf_qtile(3, false) == mf_qtile(3, true) && mf_qtile(1, false) == mf_qtile(1, true), "query tile");
     const int cap = mf_cap(kp);
     const int64_t nqt = (nq + qtile - 1) / qtile;
     const int spg_max = (MF_PH2_MAX / cap) / 8 * 8;               // slices whose lists fit one finish block
@@ -1059,16 +1113,6 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
         if (v >= 8 && v <= spg_max * gmax && n / v >= MF_TILE_R) ns = v;
     }
     const int ngroups = (ns + spg_max - 1) / spg_max;
-    // Up to 128 queries (four active waves, one per SIMD) the scan is HBM-bound: deep prefetch, 32x32x16.  Beyond,
-    // both waves of every SIMD carry MFMAs and the variant with the mid-unit barrier wins, also where the slice is
-    // still read by one or two query tiles only (100M x 384, one device: Q = 256 20.7 -> 18.9 ms, Q = 512
-    // 36.5 -> 33.3 ms, Q = 128 13.9 vs 13.85 ms; profiles/r02_midq_variants.jsonl)
-    plan->pd = (nq <= 128) ? 3 : 2;
-    if (const char* e = getenv("MI_MFMA_PD")) { const int v = atoi(e); if (v == 2 || v == 3) plan->pd = v; }
-    // MFMA shape: 16x16x32 in the MFMA-bound variant (+8.6 % at 100M x 384 on one device: same
-    // cycles, higher sustained clock); MI_MFMA_M16=0 selects 32x32x16 for A/B runs
-    plan->m16 = (plan->pd == 2) ? 1 : 0;
-    if (const char* e = getenv("MI_MFMA_M16")) plan->m16 = (atoi(e) != 0 && plan->pd == 2) ? 1 : 0;
     plan->kprime = kp;
     plan->cap = cap;
     plan->nslices = ns;
