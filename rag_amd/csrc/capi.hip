@@ -893,14 +893,21 @@ extern "C" void mi_comm_destroy(mi_comm* c)
 extern "C" int mi_comm_size(const mi_comm* c) { return c ? c->nranks : -1; }
 extern "C" int mi_comm_rank(const mi_comm* c) { return c ? c->rank : -1; }
 
-extern "C" int mi_comm_all_gather_dev(mi_comm* c, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream)
+// caller holds c->mu: an RCCL communicator takes one collective at a time
+static int all_gather_locked(mi_comm* c, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream)
 {
-    MI_REQUIRE(c && send_dev && recv_dev, "mi_comm_all_gather_dev: NULL argument");
     DeviceGuard guard(c->ctx->device);
     hipStream_t st = mi_pick_stream(stream, c->ctx->stream);
     const int rc = g_rccl.all_gather(send_dev, recv_dev, bytes_per_rank, /* ncclUint8 */ 1, c->comm, st);
     if (rc != 0) return rccl_fail("ncclAllGather", rc);
     return MI_OK;
+}
+
+extern "C" int mi_comm_all_gather_dev(mi_comm* c, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream)
+{
+    MI_REQUIRE(c && send_dev && recv_dev, "mi_comm_all_gather_dev: NULL argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    return all_gather_locked(c, send_dev, recv_dev, bytes_per_rank, stream);
 }
 
 // The whole sharded search of one rank: local exact top-k into the rank's packed block -> ONE all-gather -> the same
@@ -918,6 +925,6 @@ extern "C" int mi_index_search_sharded_dev(mi_index* idx, mi_comm* c, int64_t nq
     MI_TRY(c->gathered.ensure(block * (size_t)c->nranks));
     char* mine = (char*)c->mine.p;
     MI_TRY(mi_index_search_dev(idx, nq, q_dev, k, (float*)mine, (int64_t*)(mine + ids_off), stream));
-    MI_TRY(mi_comm_all_gather_dev(c, mine, c->gathered.p, block, stream));
+    MI_TRY(all_gather_locked(c, mine, c->gathered.p, block, stream));
     return mi_topk_merge_packed_dev(c->ctx, idx->metric, nq, c->nranks, k, c->gathered.p, k, out_scores_dev, out_ids_dev, stream);
 }
