@@ -1616,7 +1616,7 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(const uint16_t* __restrict
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int hp = lane >> 5, col = lane & 31;
-    const int head = blockIdx.x, b = blockIdx.y;
+    const int head = blockIdx.x;
     const int H3 = 3 * H;
     const uint16_t* base = qkv + tok0 * H3 + head * 32;
     // blocked layouts ([tokens / 128][columns / 32][128][32], written by gemm_ws_kernel / read by
