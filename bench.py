@@ -200,11 +200,19 @@ def main() -> int:
     if world != args.gpus and world > 1:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     ngpu = world
+    # Rehearsal switches (a one-GPU box cannot run RCCL with two ranks on one device): MI355RAG_BENCH_BACKEND=gloo carries the
+    # collectives, MI355RAG_BENCH_ONE_GPU=1 puts every rank on device 0.  The driver's runs use neither.
+    backend = os.environ.get("MI355RAG_BENCH_BACKEND", "nccl")
+    if os.environ.get("MI355RAG_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from rag_amd.distributed import ShardedFlatIndex
     from rag_amd.index import FlatIndex
