@@ -182,6 +182,43 @@ int  mi_comm_all_gather_dev(mi_comm* comm, const void* send_dev, void* recv_dev,
 int  mi_index_search_sharded_dev(mi_index* idx, mi_comm* comm, int64_t nq, const float* q_dev, int k,
                                  float* out_scores_dev, int64_t* out_ids_dev, void* stream);
 
+/* ------------------------------------------------------------------ one index over several GPUs, one host process
+ * advanced_rag.py is ONE Python process (module-global chain, :336-337) that builds one store (FAISS.from_documents, :295)
+ * and searches it from whatever thread LangChain picks (:296, :409): a drop-in for it that uses the whole node cannot be
+ * one-process-per-rank.  A mi_multi_index owns one ctx + one flat index per listed device (SURVEY.md section 8b sketched
+ * this as mi_init(device_ids, n_devices)).  Rows are placed round-robin by blocks of MI_MULTI_BLOCK rows: global row g
+ * lives on shard (g / block) % G, so appends keep working and shards stay balanced; ids reported are global row numbers.
+ * A search broadcasts the queries (peer copies, or one host-to-device copy per GPU), runs mi_index_search_dev on every
+ * shard from its own host thread, copies the G packed blocks peer-to-peer to the first device and merges them there with
+ * mi_topk_merge_packed_dev -- no RCCL inside one process -- and returns the single-index answer bit for bit.
+ * A device may be listed more than once (one shard per entry).  Every function takes the handle's mutex. */
+#define MI_MULTI_BLOCK 16384
+typedef struct mi_multi_index mi_multi_index;
+int  mi_multi_index_create(const int* device_ids, int n_devices, int dim, int metric, int dtype, mi_multi_index** out);
+void mi_multi_index_destroy(mi_multi_index* m);
+/* Rows per placement block (default MI_MULTI_BLOCK); only while the index is empty. */
+int  mi_multi_index_set_block_rows(mi_multi_index* m, int64_t rows);
+int  mi_multi_index_devices(const mi_multi_index* m);
+int64_t mi_multi_index_ntotal(const mi_multi_index* m);
+int64_t mi_multi_index_shard_ntotal(const mi_multi_index* m, int shard);
+int  mi_multi_index_set_mode(mi_multi_index* m, int mode);
+int  mi_multi_index_reserve(mi_multi_index* m, int64_t n_rows);
+/* index.add (advanced_rag.py:295): host fp32 rows [n][dim]; the shards receive their blocks concurrently. */
+int  mi_multi_index_add(mi_multi_index* m, int64_t n, const float* x_host);
+int  mi_multi_index_add_raw(mi_multi_index* m, int64_t n, const void* x_host, int src_dtype);
+int  mi_multi_index_add_synthetic(mi_multi_index* m, int64_t n, uint64_t seed, int normalize);
+int  mi_multi_index_reset(mi_multi_index* m);
+/* Rows [row0, row0+n) in global order; raw != 0: the storage type (fp32, or bf16 bit patterns), else fp32. */
+int  mi_multi_index_get_rows(mi_multi_index* m, int64_t row0, int64_t n, void* out_host, int raw);
+/* index.search (advanced_rag.py:296): host buffers in and out. */
+int  mi_multi_index_search(mi_multi_index* m, int64_t nq, const float* q_host, int k, float* out_scores, int64_t* out_ids);
+/* q_dev and both outputs on the FIRST listed device; `stream` is a stream of that device.  Complete on return. */
+int  mi_multi_index_search_dev(mi_multi_index* m, int64_t nq, const float* q_dev, int k,
+                               float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+/* out[0] queries searched, out[1] (query, shard) searches certified by the MFMA path, out[2] re-run on the exact
+ * path, out[3] rows. */
+int  mi_multi_index_stats(const mi_multi_index* m, int64_t out[4]);
+
 /* ------------------------------------------------------------------ encoder
  * Replaces HuggingFaceEmbeddings(...).embed_documents / embed_query
  * (advanced_rag.py:104-107; sentence-transformers -> transformers BertModel,

@@ -78,6 +78,22 @@ SYMBOLS = {
     "mi_comm_rank": (_i32, [_vp]),
     "mi_comm_all_gather_dev": (_i32, [_vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "mi_index_search_sharded_dev": (_i32, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "mi_multi_index_create": (_i32, [ctypes.POINTER(ctypes.c_int), _i32, _i32, _i32, _i32, _pp]),
+    "mi_multi_index_destroy": (None, [_vp]),
+    "mi_multi_index_set_block_rows": (_i32, [_vp, _i64]),
+    "mi_multi_index_devices": (_i32, [_vp]),
+    "mi_multi_index_ntotal": (_i64, [_vp]),
+    "mi_multi_index_shard_ntotal": (_i64, [_vp, _i32]),
+    "mi_multi_index_set_mode": (_i32, [_vp, _i32]),
+    "mi_multi_index_reserve": (_i32, [_vp, _i64]),
+    "mi_multi_index_add": (_i32, [_vp, _i64, _vp]),
+    "mi_multi_index_add_raw": (_i32, [_vp, _i64, _vp, _i32]),
+    "mi_multi_index_add_synthetic": (_i32, [_vp, _i64, _u64, _i32]),
+    "mi_multi_index_reset": (_i32, [_vp]),
+    "mi_multi_index_get_rows": (_i32, [_vp, _i64, _i64, _vp, _i32]),
+    "mi_multi_index_search": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp]),
+    "mi_multi_index_search_dev": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "mi_multi_index_stats": (_i32, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "mi_encoder_blob_elems": (_i64, [_cfgp]),
     "mi_encoder_create": (_i32, [_vp, _cfgp, _vp, ctypes.c_size_t, _pp]),
     "mi_encoder_destroy": (None, [_vp]),

@@ -302,7 +302,10 @@ extern "C" int mi_index_add_raw(mi_index* idx, int64_t n, const void* x_host, in
     return add_host_locked(idx, n, x_host, src_dtype);
 }
 
-extern "C" int mi_index_add_synthetic(mi_index* idx, int64_t n, uint64_t seed, int normalize)
+// Appends n synthetic rows that are rows [global_row0, global_row0 + n) of the generator's sequence (global_row0 < 0:
+// the index's own numbering, id_base + ntotal).  mi_multi_index_add_synthetic places blocks of one corpus on several
+// shards through this.
+int mi_index_add_synthetic_at(mi_index* idx, int64_t n, uint64_t seed, int normalize, int64_t global_row0)
 {
     MI_REQUIRE(idx && n >= 0, "mi_index_add_synthetic: bad argument");
     if (n == 0) return MI_OK;
@@ -310,17 +313,23 @@ extern "C" int mi_index_add_synthetic(mi_index* idx, int64_t n, uint64_t seed, i
     DeviceGuard g(idx->ctx->device);
     hipStream_t st = idx->ctx->stream;
     MI_TRY(grow_for(idx, n));
+    const int64_t g0 = global_row0 >= 0 ? global_row0 : idx->id_base + idx->n;
     // chunked so the launch grid stays small
     const int64_t chunk = (int64_t)1 << 24;
     for (int64_t off = 0; off < n; off += chunk) {
         const int64_t m = (n - off < chunk) ? n - off : chunk;
         MI_TRY(mi_launch_synth(st, row_ptr(idx, idx->n + off), idx->dtype, m, idx->d, idx->d_pad, seed,
-                               idx->id_base + idx->n + off, normalize));
+                               g0 + off, normalize));
         MI_TRY(mi_launch_row_norms(st, row_ptr(idx, idx->n + off), idx->dtype, m, idx->d_pad, idx->xx + idx->n + off, idx->max_xx));
     }
     MI_HIP(hipStreamSynchronize(st));      // later searches may run on a caller's stream
     idx->n += n;
     return MI_OK;
+}
+
+extern "C" int mi_index_add_synthetic(mi_index* idx, int64_t n, uint64_t seed, int normalize)
+{
+    return mi_index_add_synthetic_at(idx, n, seed, normalize, -1);
 }
 
 extern "C" int64_t mi_index_ntotal(const mi_index* idx) { return idx ? idx->n : -1; }
@@ -738,6 +747,9 @@ static int merge_any(mi_ctx* ctx, hipStream_t st, int metric, int64_t nq, int64_
         }
         MI_TRY(mi_launch_merge_ex(st, metric, qc, (int)cm, (int)cm, cs, ci, ck, cls, cli, cq, k, out_s + q0 * k, out_i + q0 * k, k));
     }
+    // the ctx's two scratch buffers serve every caller and stream: the next multi-pass merge (maybe on another stream)
+    // must not start while this one still reads them.  Rare path (more than 4096 pairs per query): a host sync is cheap.
+    MI_HIP(hipStreamSynchronize(st));
     return MI_OK;
 }
 
@@ -883,7 +895,7 @@ extern "C" void mi_comm_destroy(mi_comm* c)
 {
     if (!c) return;
     DeviceGuard guard(c->ctx->device);
-    (void)hipStreamSynchronize(c->ctx->stream);
+    (void)hipDeviceSynchronize();          // collectives may have been enqueued on a caller's stream, not only the ctx's
     if (c->comm) (void)g_rccl.comm_destroy(c->comm);
     c->mine.release();
     c->gathered.release();
@@ -917,6 +929,11 @@ extern "C" int mi_index_search_sharded_dev(mi_index* idx, mi_comm* c, int64_t nq
 {
     MI_REQUIRE(idx && c && q_dev && out_scores_dev && out_ids_dev && nq > 0 && k > 0, "mi_index_search_sharded_dev: bad argument");
     MI_REQUIRE(idx->ctx == c->ctx, "mi_index_search_sharded_dev: the index and the communicator belong to different contexts");
+    // everything that can fail for a reason the other ranks do not share is checked BEFORE the collective: a rank that
+    // returns early leaves its peers blocked in ncclAllGather (then the caller must tear the communicator down)
+    MI_REQUIRE(nq < ((int64_t)1 << 24), "mi_index_search_sharded_dev: nq %lld out of range", (long long)nq);
+    if (k > MI_MAX_K) { mi_set_error("mi_index_search_sharded_dev: k=%d exceeds MI_MAX_K=%d", k, MI_MAX_K); return MI_ERR_UNSUPPORTED; }
+    MI_REQUIRE((int64_t)c->nranks * k < ((int64_t)1 << 24), "mi_index_search_sharded_dev: nranks*k out of range");
     DeviceGuard guard(c->ctx->device);
     std::lock_guard<std::mutex> lk(c->mu);
     size_t ids_off = 0, block = 0;
@@ -924,7 +941,21 @@ extern "C" int mi_index_search_sharded_dev(mi_index* idx, mi_comm* c, int64_t nq
     MI_TRY(c->mine.ensure(block));
     MI_TRY(c->gathered.ensure(block * (size_t)c->nranks));
     char* mine = (char*)c->mine.p;
-    MI_TRY(mi_index_search_dev(idx, nq, q_dev, k, (float*)mine, (int64_t*)(mine + ids_off), stream));
+    hipStream_t st = mi_pick_stream(stream, c->ctx->stream);
+    int rc = mi_index_search_dev(idx, nq, q_dev, k, (float*)mine, (int64_t*)(mine + ids_off), stream);
+    if (rc != MI_OK) {
+        // keep the collective matched on every rank: this rank contributes an all-padding block and still reports its error
+        char msg[512];
+        strncpy(msg, mi_last_error(), sizeof(msg) - 1); msg[sizeof(msg) - 1] = 0;
+        (void)mi_launch_fill_pad(st, idx->metric, nq, k, (float*)mine, (int64_t*)(mine + ids_off), k);
+        (void)all_gather_locked(c, mine, c->gathered.p, block, stream);
+        (void)hipStreamSynchronize(st);
+        mi_set_error("%s", msg);
+        return rc;
+    }
     MI_TRY(all_gather_locked(c, mine, c->gathered.p, block, stream));
-    return mi_topk_merge_packed_dev(c->ctx, idx->metric, nq, c->nranks, k, c->gathered.p, k, out_scores_dev, out_ids_dev, stream);
+    MI_TRY(mi_topk_merge_packed_dev(c->ctx, idx->metric, nq, c->nranks, k, c->gathered.p, k, out_scores_dev, out_ids_dev, stream));
+    // `mine` / `gathered` belong to the communicator and the next call may come on another stream: done before return
+    MI_HIP(hipStreamSynchronize(st));
+    return MI_OK;
 }

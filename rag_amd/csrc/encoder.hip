@@ -1996,6 +1996,10 @@ struct mi_encoder {
     hipEvent_t ev_pin[2] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // ev1 also orders the shared workspace: it is recorded behind every pass, and a pass enqueued on ANOTHER stream than
+    // the last one (a PyTorch stream through *_dev, then the ctx stream through a host entry point) waits on it first
+    hipStream_t last_st = nullptr;
+    bool have_last = false;
     // cross-encoder head (mi_encoder_set_head): pooler W[H][H] b[H], classifier W[nl][H] b[nl], fp32 on device
     float* head = nullptr;
     int nlabels = 0;
@@ -2299,7 +2303,12 @@ static int ensure_ws(mi_encoder* e, int64_t T, hipStream_t st)
 {
     const size_t need = encoder_ws_need(e->cfg, T);
     if (need <= e->ws_bytes) return MI_OK;
-    if (e->ws) { MI_HIP(hipStreamSynchronize(st)); (void)hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0; }
+    if (e->ws) {
+        // the last pass may still be running on another stream than this one
+        if (e->have_last) MI_HIP(hipEventSynchronize(e->ev1));
+        MI_HIP(hipStreamSynchronize(st));
+        (void)hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0;
+    }
     hipError_t er = hipMalloc(&e->ws, need);
     if (er != hipSuccess) { e->ws = nullptr; mi_set_error("encode: hipMalloc(%zu) for the workspace failed: %s", need, hipGetErrorString(er)); return MI_ERR_OOM; }
     e->ws_bytes = need;
@@ -2322,6 +2331,14 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     const int64_t T = seq_start ? T_packed : B * L;
     MI_REQUIRE(T < ((int64_t)1 << 31) / 16, "encode: too many tokens in one call (%lld)", (long long)T);
     const size_t need = encoder_ws_need(c, T);
+    // Under HIP graph capture (mi_encoder_encode_dev_noalloc's callers) nothing may be recorded on or waited for from outside
+    // the capture: the timing events would become graph nodes and a later mi_encoder_last_time would fail on them.
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap_status);
+    const bool capturing = cap_status != hipStreamCaptureStatusNone;
+    // One workspace (and one `scratch` array) serves every pass of this encoder; passes on one stream serialise by themselves,
+    // a pass on another stream than the previous one waits for that one's end.
+    if (!capturing && e->have_last && e->last_st != st) MI_HIP(hipStreamWaitEvent(st, e->ev1, 0));
     void* wsp = nullptr;
     if (ws_ext) {
         if (need > ws_ext_bytes) {
@@ -2363,7 +2380,7 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     const bool fused_front = fused_ffn && !front_off;
     // MI_FFN2=0: the first form of the fused FFN (ffn_ln_kernel) instead of the K-split one (ffn2_kernel); read per call (A/B)
     const bool ffn2 = !(getenv("MI_FFN2") && atoi(getenv("MI_FFN2")) == 0);
-    MI_HIP(hipEventRecord(e->ev0, st));
+    if (!capturing) MI_HIP(hipEventRecord(e->ev0, st));
     if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, types, pos_ids, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, types, pos_ids, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     for (const LayerW& lw : e->layers) {
@@ -2416,9 +2433,13 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
         cls_head_kernel<<<(unsigned)((B + CLS_PB - 1) / CLS_PB), (unsigned)((H + 63) / 64 * 64), 2 * CLS_PB * HH * sizeof(float), st>>>(
             h, seq_start, L, H, hw, hw + HH * HH, hw + HH * HH + HH, hw + HH * HH + HH + (size_t)e->nlabels * HH, e->nlabels, B, out_logits);
     }
-    MI_HIP(hipEventRecord(e->ev1, st));
     MI_HIP(hipGetLastError());
-    e->timed = true;
+    if (!capturing) {
+        MI_HIP(hipEventRecord(e->ev1, st));
+        e->timed = true;
+        e->last_st = st;
+        e->have_last = true;
+    }
     e->st_seqs += B;
     e->st_tokens += T;
     if (bulk) e->st_bulk += 1; else e->st_latency += 1;

@@ -176,11 +176,17 @@ def _load_tokenizer(path: str, max_len: int):
 
 
 class MI355Embeddings:
-    """HuggingFaceEmbeddings-compatible: model_name (local dir), model_kwargs, encode_kwargs."""
+    """HuggingFaceEmbeddings-compatible: model_name (local dir), model_kwargs, encode_kwargs.
+
+    Extensions (none changes a result): `devices=[0, ..., 7]` (or model_kwargs={"devices": [...]}) keeps one encoder per
+    listed GPU in this one process and splits every bulk call over them -- pure data parallel, no collective, input
+    order kept (BASELINE config 3 from the single process advanced_rag.py is); `slab_texts` is the number of texts
+    tokenised per step of the host pipeline below."""
 
     def __init__(self, model_name: str, cache_folder: Optional[str] = None,
                  model_kwargs: Optional[Dict[str, Any]] = None, encode_kwargs: Optional[Dict[str, Any]] = None,
-                 multi_process: bool = False, max_seq_length: int = 256, **_: Any):
+                 multi_process: bool = False, max_seq_length: int = 256, devices: Optional[List[int]] = None,
+                 slab_texts: int = 8192, **_: Any):
         self.model_name = model_name
         self.model_kwargs = dict(model_kwargs or {})
         self.encode_kwargs = dict(encode_kwargs or {})
@@ -188,14 +194,19 @@ class MI355Embeddings:
         # the reference passes "cpu" (advanced_rag.py:106); this build has only the GPU path
         if isinstance(dev, str):
             dev = int(dev.split(":")[1]) if ":" in dev else 0
-        self.device = int(dev)
+        devices = devices if devices is not None else self.model_kwargs.get("devices")
+        self.devices = [int(x) for x in devices] if devices else [int(dev)]
+        self.device = self.devices[0]
         self._batch_size_set = "batch_size" in self.encode_kwargs
         self.batch_size = int(self.encode_kwargs.get("batch_size", 32))
         normalize = bool(self.encode_kwargs.get("normalize_embeddings", True))
         cfg, blob = load_local_dir(model_name, normalize=normalize)
         self.max_seq_length = min(int(max_seq_length), int(cfg.max_position_embeddings))
         self.tokenizer = _load_tokenizer(model_name, self.max_seq_length)
-        self.encoder = Encoder(cfg, blob, device=self.device)
+        self.encoders = [Encoder(cfg, blob, device=d) for d in self.devices]
+        self.encoder = self.encoders[0]
+        self.slab_texts = max(1, int(slab_texts))
+        self.last_timing: Dict[str, float] = {}
 
     # ---- tokenisation; the length-sorted batching of sentence-transformers' encode loop lives in the library
     def _tokenize(self, texts: List[str]):
@@ -203,26 +214,89 @@ class MI355Embeddings:
 
     @staticmethod
     def _to_csr(toks) -> tuple:
-        lens = np.fromiter((len(t) for t in toks), dtype=np.int64, count=len(toks))
-        offsets = np.zeros(len(toks) + 1, dtype=np.int64)
-        np.cumsum(lens, out=offsets[1:])
-        flat = np.fromiter((i for t in toks for i in t), dtype=np.int32, count=int(offsets[-1]))
+        """Lists of token ids -> (flat int32 ids, int64 offsets [n + 1]).  One array conversion per sequence and one
+        concatenate: a per-token Python generator here cost as much as the GPU's whole forward at bulk scale."""
+        n = len(toks)
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        if n == 0:
+            return np.zeros(0, dtype=np.int32), offsets
+        parts = [np.asarray(t, dtype=np.int32) for t in toks]
+        np.cumsum(np.fromiter((p.size for p in parts), dtype=np.int64, count=n), out=offsets[1:])
+        flat = np.concatenate(parts) if offsets[-1] else np.zeros(0, dtype=np.int32)
         return flat, offsets
+
+    def _tokenize_csr(self, texts: List[str]) -> tuple:
+        return self._to_csr(self._tokenize([t.replace("\n", " ") for t in texts]))
+
+    def _encode_csr(self, flat_ids: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+        kw = dict(max_len=self.max_seq_length, max_batch=self.batch_size if self._batch_size_set else 0)
+        n = offsets.size - 1
+        G = len(self.encoders)
+        if G == 1 or n < 2 * G:
+            return self.encoder.encode_ragged(flat_ids, offsets, **kw)
+        # one host thread per GPU (ctypes releases the GIL): contiguous ranges cut at equal token counts
+        from concurrent.futures import ThreadPoolExecutor
+        cuts = np.searchsorted(offsets, np.linspace(0, offsets[-1], G + 1)[1:-1]).astype(np.int64)
+        bounds = np.concatenate([[0], np.clip(cuts, 0, n), [n]])
+        out = np.empty((n, self.encoder.hidden_size), dtype=np.float32)
+
+        def run(g):
+            lo, hi = int(bounds[g]), int(bounds[g + 1])
+            if hi > lo:
+                out[lo:hi] = self.encoders[g].encode_ragged(flat_ids[offsets[lo]:offsets[hi]], offsets[lo:hi + 1] - offsets[lo], **kw)
+        with ThreadPoolExecutor(max_workers=G) as ex:
+            list(ex.map(run, range(G)))
+        return out
 
     def embed_tokenized(self, flat_ids: np.ndarray, offsets: np.ndarray) -> np.ndarray:
         """Token ids in (CSR), embeddings out, input order: the step of embed_documents below the tokenizer.
         `encode_kwargs["batch_size"]` caps the rows per pass only when the caller set it; by default a pass is cut
         by the library's token budget, so a bulk call (FAISS.from_documents, advanced_rag.py:295) runs the fused
         bulk kernels."""
-        return self.encoder.encode_ragged(flat_ids, offsets, max_len=self.max_seq_length,
-                                          max_batch=self.batch_size if self._batch_size_set else 0)
+        return self._encode_csr(np.ascontiguousarray(flat_ids, dtype=np.int32), np.ascontiguousarray(offsets, dtype=np.int64))
 
     def embed_documents_array(self, texts: List[str]) -> np.ndarray:
-        texts = [t.replace("\n", " ") for t in texts]
-        if not texts:
+        """Strings in, [n][hidden] fp32 out.  Bulk calls run as a two-stage host pipeline over slabs of `slab_texts`
+        texts: a worker thread tokenises slab i + 1 (the Rust tokenizer releases the GIL and uses the host cores)
+        while this thread has slab i on the GPU (mi_encoder_encode_ragged, GIL released).  Per-slab results land at
+        their input positions, so order and bits equal the one-shot call's."""
+        import time
+        n = len(texts)
+        if n == 0:
             return np.zeros((0, self.encoder.hidden_size), dtype=np.float32)
-        flat, offsets = self._to_csr(self._tokenize(texts))
-        return self.embed_tokenized(flat, offsets)
+        t_all = time.perf_counter()
+        S = self.slab_texts
+        if n <= S:
+            t0 = time.perf_counter()
+            flat, offsets = self._tokenize_csr(texts)
+            t1 = time.perf_counter()
+            out = self._encode_csr(flat, offsets)
+            t2 = time.perf_counter()
+            self.last_timing = {"tokenize_s": t1 - t0, "encode_s": t2 - t1, "total_s": t2 - t_all, "slabs": 1, "tokens": int(offsets[-1])}
+            return out
+        from concurrent.futures import ThreadPoolExecutor
+        out = np.empty((n, self.encoder.hidden_size), dtype=np.float32)
+        tok_s = enc_s = 0.0
+        tokens = 0
+
+        def tok(i0):
+            t0 = time.perf_counter()
+            r = self._tokenize_csr(texts[i0:i0 + S])
+            return r, time.perf_counter() - t0
+        with ThreadPoolExecutor(max_workers=1) as ex:
+            nxt = ex.submit(tok, 0)
+            for i0 in range(0, n, S):
+                (flat, offsets), dt = nxt.result()
+                tok_s += dt
+                if i0 + S < n:
+                    nxt = ex.submit(tok, i0 + S)
+                t0 = time.perf_counter()
+                out[i0:i0 + S] = self._encode_csr(flat, offsets)
+                enc_s += time.perf_counter() - t0
+                tokens += int(offsets[-1])
+        self.last_timing = {"tokenize_s": tok_s, "encode_s": enc_s, "total_s": time.perf_counter() - t_all,
+                            "slabs": (n + S - 1) // S, "tokens": tokens}
+        return out
 
     def embed_documents(self, texts: List[str]) -> List[List[float]]:
         return self.embed_documents_array(list(texts)).tolist()

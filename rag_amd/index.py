@@ -163,6 +163,115 @@ class FlatIndex:
         return {"ms": ms.value, "launches": n.value, "kind": "mfma_bf16" if kind.value == 1 else "exact_f32"}
 
 
+class MultiFlatIndex:
+    """ONE exact flat index over several GPUs, driven from this one process (mi_multi_index_*): the store behind
+    `FAISS.from_documents(..., devices=[0, ..., 7])`.  Same surface as FlatIndex; ids are global row numbers in insertion
+    order; the answer equals the single-GPU answer in ids and score bits.  `devices` may repeat a device (one shard
+    per entry)."""
+
+    def __init__(self, d: int, metric: str = "l2", dtype: str = "f32", devices=(0,), block_rows: Optional[int] = None):
+        self._lib = _capi.load()
+        self.d = int(d)
+        self.metric = {"l2": METRIC_L2, "ip": METRIC_IP}[metric.lower()]
+        self.dtype = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "float32": DTYPE_F32,
+                      "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16}[dtype.lower()]
+        self.devices = [int(x) for x in devices]
+        if not self.devices:
+            raise ValueError("MultiFlatIndex: devices must name at least one GPU")
+        self.device = self.devices[0]
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        h = ctypes.c_void_p()
+        _capi.check(self._lib.mi_multi_index_create(arr, len(self.devices), self.d, self.metric, self.dtype, ctypes.byref(h)))
+        self._h = h
+        if block_rows is not None:
+            _capi.check(self._lib.mi_multi_index_set_block_rows(self._h, int(block_rows)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                self._lib.mi_multi_index_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    @property
+    def ntotal(self) -> int:
+        return int(self._lib.mi_multi_index_ntotal(self._h))
+
+    def shard_ntotal(self, shard: int) -> int:
+        return int(self._lib.mi_multi_index_shard_ntotal(self._h, int(shard)))
+
+    def reserve(self, n_rows: int) -> None:
+        _capi.check(self._lib.mi_multi_index_reserve(self._h, int(n_rows)))
+
+    def add(self, x) -> None:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError(f"add: expected [n][{self.d}] array, got {x.shape}")
+        _capi.check(self._lib.mi_multi_index_add(self._h, x.shape[0], _np_ptr(x)))
+
+    def add_raw(self, x: np.ndarray) -> None:
+        if x.dtype == np.uint16:
+            src = DTYPE_BF16
+        elif x.dtype == np.float32:
+            src = DTYPE_F32
+        else:
+            raise ValueError("add_raw: float32 or uint16 (bf16 bit patterns) rows")
+        x = np.ascontiguousarray(x)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError(f"add_raw: expected [n][{self.d}] array, got {x.shape}")
+        _capi.check(self._lib.mi_multi_index_add_raw(self._h, x.shape[0], _np_ptr(x), src))
+
+    def add_synthetic(self, n: int, seed: int = 0, normalize: bool = True) -> None:
+        _capi.check(self._lib.mi_multi_index_add_synthetic(self._h, int(n), int(seed), int(normalize)))
+
+    def search(self, q, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError(f"search: expected [nq][{self.d}] array, got {q.shape}")
+        nq = q.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _capi.check(self._lib.mi_multi_index_search(self._h, nq, _np_ptr(q), int(k), _np_ptr(D), _np_ptr(I)))
+        return D, I
+
+    def search_torch(self, q, k: int):
+        """q: contiguous fp32 CUDA tensor [nq][d] on the FIRST listed device; results on that device."""
+        import torch
+        if (not q.is_cuda or q.dtype != torch.float32 or q.dim() != 2 or q.shape[1] != self.d or not q.is_contiguous()
+                or q.device.index != self.devices[0]):
+            raise ValueError(f"search_torch: need a contiguous fp32 [nq][d] tensor on cuda:{self.devices[0]}")
+        nq = q.shape[0]
+        D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        _capi.check(self._lib.mi_multi_index_search_dev(self._h, nq, ctypes.c_void_p(q.data_ptr()), int(k),
+                                                        ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()),
+                                                        _capi.stream_arg(q.device)))
+        return D, I
+
+    def reconstruct_n(self, row0: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.d), dtype=np.float32)
+        _capi.check(self._lib.mi_multi_index_get_rows(self._h, int(row0), int(n), _np_ptr(out), 0))
+        return out
+
+    def reconstruct_raw(self, row0: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.d), dtype=np.float32 if self.dtype == DTYPE_F32 else np.uint16)
+        _capi.check(self._lib.mi_multi_index_get_rows(self._h, int(row0), int(n), _np_ptr(out), 1))
+        return out
+
+    def reset(self) -> None:
+        _capi.check(self._lib.mi_multi_index_reset(self._h))
+
+    def set_mode(self, mode: int) -> None:
+        _capi.check(self._lib.mi_multi_index_set_mode(self._h, int(mode)))
+
+    def stats(self) -> dict:
+        out = (ctypes.c_int64 * 4)()
+        _capi.check(self._lib.mi_multi_index_stats(self._h, out))
+        return {"queries": out[0], "fast": out[1], "exact": out[2], "rows": out[3]}
+
+
 def topk_merge_torch(scores, ids, k: int, metric: str = "ip", device: Optional[int] = None):
     """Merge best-first lists: scores/ids CUDA tensors [nq][m]; returns ([nq][k], [nq][k])."""
     import torch

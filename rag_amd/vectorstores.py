@@ -17,7 +17,7 @@ from typing import Any, Callable, Dict, Iterable, List, Optional, Sequence, Tupl
 import numpy as np
 
 from .documents import Document
-from .index import FlatIndex
+from .index import FlatIndex, MultiFlatIndex
 
 EUCLIDEAN_DISTANCE = "EUCLIDEAN_DISTANCE"
 MAX_INNER_PRODUCT = "MAX_INNER_PRODUCT"
@@ -236,13 +236,18 @@ class MI355VectorStore:
     def __from(cls, texts: List[str], embeddings: np.ndarray, embedding: Any, metadatas: Optional[List[dict]] = None,
                ids: Optional[List[str]] = None, normalize_L2: bool = False,
                distance_strategy: str = EUCLIDEAN_DISTANCE, dtype: str = "f32", device: int = 0,
-               **kwargs: Any) -> "MI355VectorStore":
+               devices: Optional[Sequence[int]] = None, **kwargs: Any) -> "MI355VectorStore":
         embeddings = np.asarray(embeddings, dtype=np.float32)
         if embeddings.ndim != 2 or embeddings.shape[0] == 0:
             # the reference path would fail on embeddings[0]; keep that an IndexError
             raise IndexError("list index out of range")
         metric = "ip" if distance_strategy == MAX_INNER_PRODUCT else "l2"
-        index = FlatIndex(embeddings.shape[1], metric=metric, dtype=dtype, device=device)
+        # devices=[0, ..., 7]: one store over several GPUs from this one process (the reference is one process,
+        # advanced_rag.py:336-337); rows round-robin by blocks, answer identical to the single-GPU store
+        if devices is not None and len(devices) > 0:
+            index = MultiFlatIndex(embeddings.shape[1], metric=metric, dtype=dtype, devices=devices)
+        else:
+            index = FlatIndex(embeddings.shape[1], metric=metric, dtype=dtype, device=device)
         store = cls(embedding, index, InMemoryDocstore(), {}, normalize_L2=normalize_L2,
                     distance_strategy=distance_strategy, **kwargs)
         store.__add(texts, embeddings, metadatas=metadatas, ids=ids)
@@ -403,7 +408,8 @@ class MI355VectorStore:
 
     @classmethod
     def load_local(cls, folder_path: str, embeddings: Any, index_name: str = "index", device: int = 0,
-                   index_factory: Optional[Callable[..., Any]] = None, **kwargs: Any) -> "MI355VectorStore":
+                   index_factory: Optional[Callable[..., Any]] = None, devices: Optional[Sequence[int]] = None,
+                   **kwargs: Any) -> "MI355VectorStore":
         import json
         import os
         with open(os.path.join(folder_path, f"{index_name}.store.json")) as f:
@@ -412,7 +418,10 @@ class MI355VectorStore:
             raise ValueError(f"{folder_path}: not a mi355rag store")
         rows = np.load(os.path.join(folder_path, f"{index_name}.rows.npy"), allow_pickle=False, mmap_mode="r")
         metric = "ip" if meta["distance_strategy"] == MAX_INNER_PRODUCT else "l2"
-        make = index_factory or (lambda d, metric, dtype: FlatIndex(d, metric=metric, dtype=dtype, device=device))
+        if devices:
+            make = index_factory or (lambda d, metric, dtype: MultiFlatIndex(d, metric=metric, dtype=dtype, devices=devices))
+        else:
+            make = index_factory or (lambda d, metric, dtype: FlatIndex(d, metric=metric, dtype=dtype, device=device))
         index = make(meta["d"], metric=metric, dtype=meta["dtype"])
         slab = max(1, (256 << 20) // (int(meta["d"]) * 4))
         for r0 in range(0, len(rows), slab):

@@ -185,3 +185,64 @@ def test_padded_and_packed_passes_in_child_processes(varlen):
     tokens, real, worst = int(f[1]), int(f[3]), float(f[5])
     assert worst < TOL, worst
     assert (tokens == real) if varlen == "1" else (tokens > real)
+
+
+def test_passes_on_two_streams_do_not_share_the_workspace_at_once(oracle_mod):
+    """every pass of an encoder uses ONE activation workspace.  encode_ids_torch enqueues on PyTorch's
+    stream and returns with its kernels still running; a host-pointer call right behind it runs on the ctx's own
+    (non-blocking) stream.  The second pass must wait for the first (the library chains them through the event it
+    records behind every pass); both results against the oracle, several rounds, sizes that re-grow the workspace."""
+    import torch
+    from rag_amd._capi import BertConfig
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import random_blob
+    vals = (1000, 384, 2, 12, 1536, 512, 2, 1e-12, 1)
+    cfg, ocfg = BertConfig(*vals), oracle_mod.BertConfig(*vals)
+    blob = random_blob(cfg, seed=12, init_range=0.05)
+    enc = Encoder(cfg, blob)
+    rng = np.random.default_rng(8)
+    big_ids = rng.integers(0, 1000, size=(192, 128)).astype(np.int32)       # 24,576 tokens: the bulk kernels, ~1 ms on the GPU
+    big_mask = np.ones_like(big_ids)
+    small_ids = rng.integers(0, 1000, size=(3, 40)).astype(np.int32)
+    small_mask = np.ones_like(small_ids)
+    rows = [0, 95, 191]
+    want_big = oracle_mod.encode(ocfg, blob, big_ids[rows], big_mask[rows])
+    want_small = oracle_mod.encode(ocfg, blob, small_ids, small_mask)
+    ids_t, mask_t = torch.from_numpy(big_ids).cuda(), torch.from_numpy(big_mask).cuda()
+    torch.cuda.synchronize()
+    for rnd in range(6):
+        if rnd == 3:                                          # a larger pass in between re-grows the workspace
+            enc.encode_ids(np.tile(big_ids, (2, 1)), np.tile(big_mask, (2, 1)))
+        Eb = enc.encode_ids_torch(ids_t, mask_t)              # no sync: still running when the next call starts
+        Es = enc.encode_ids(small_ids, small_mask)            # ctx stream
+        Eb2 = enc.encode_ids_torch(ids_t, mask_t)             # and back onto PyTorch's stream
+        torch.cuda.synchronize()
+        assert np.all(_cos_err(Es, want_small) < TOL), rnd
+        assert np.all(_cos_err(Eb.cpu().numpy()[rows], want_big) < TOL), rnd
+        assert torch.equal(Eb, Eb2), rnd
+
+
+def test_slab_pipeline_equals_the_one_shot_call(tmp_path):
+    """embed_documents_array on more texts than one slab: the worker thread tokenises slab i + 1 while slab i is on the GPU;
+    same rows in the same order as the one-shot call (a slab boundary changes which sequences share a pass and
+    so which kernel family / GEMM tiling the pass takes -- bf16-level differences, far inside the 1e-3 bar -- never
+    which text a row belongs to)."""
+    from rag_amd import HuggingFaceEmbeddings
+    from tests.test_retrievers import _write_model_dir
+    words = ["the", "cat", "sat", "on", "mat", "dogs", "chase", "red", "was", "flat", "index", "row"]
+    _write_model_dir(str(tmp_path / "m"), hidden=384, layers=2, heads=12, inter=1536)
+    rng = np.random.default_rng(4)
+    texts = [" ".join(rng.choice(words, size=int(rng.integers(1, 61)))) for _ in range(1500)]
+    texts[17] = "line one\nline two"
+    one = HuggingFaceEmbeddings(model_name=str(tmp_path / "m"), max_seq_length=64)
+    E1 = one.embed_documents_array(texts)
+    assert one.last_timing["slabs"] == 1
+    slabs = HuggingFaceEmbeddings(model_name=str(tmp_path / "m"), max_seq_length=64, slab_texts=256)
+    E2 = slabs.embed_documents_array(texts)
+    assert slabs.last_timing["slabs"] == 6 and slabs.last_timing["tokens"] == one.last_timing["tokens"]
+    assert E2.shape == E1.shape and np.all(_cos_err(E1, E2) < 5e-5), _cos_err(E1, E2).max()
+    # several encoders in this process (one per listed device; device 0 twice on a one-GPU box): same rows, same order
+    multi = HuggingFaceEmbeddings(model_name=str(tmp_path / "m"), max_seq_length=64, devices=[0, 0, 0], slab_texts=700)
+    E3 = multi.embed_documents_array(texts)
+    assert E3.shape == E1.shape and np.all(_cos_err(E1, E3) < 5e-5), _cos_err(E1, E3).max()
+    assert sum(e.stats()["sequences"] for e in multi.encoders) == 1500 and all(e.stats()["sequences"] > 0 for e in multi.encoders)

@@ -384,6 +384,27 @@ def test_plan_overrides_do_not_change_the_answer(env):
     assert out.returncode == 0 and "OK" in out.stdout, (env, out.stdout[-500:], out.stderr[-2000:])
 
 
+def _exact_cross_check(idx, Q, D, I, k, planted_n):
+    """at sizes the oracle cannot follow, 64 of the queries (the planted ones included) are answered
+    a second time by MODE_EXACT -- search_exact.hip, an independent kernel family (fp32 matrix pipe / VALU fmaf chains +
+    radix select) that is held to the oracle's bits at every smaller size -- and must agree with the MFMA path's answer
+    in ids and score bits.  A true neighbour the MFMA filter dropped would show here."""
+    from rag_amd.index import MODE_EXACT, MODE_FAST
+    nq = Q.shape[0]
+    sel = sorted(set(range(planted_n)) | set(np.linspace(planted_n, nq - 1, 64 - planted_n).astype(int).tolist()))
+    before = idx.stats()
+    idx.set_mode(MODE_EXACT)
+    try:
+        De, Ie = idx.search(np.ascontiguousarray(Q[sel]), k)
+    finally:
+        idx.set_mode(MODE_FAST)
+    after = idx.stats()
+    assert idx.last_scan_time()["kind"] == "exact_f32" and after["exact"] - before["exact"] == len(sel), (before, after)
+    np.testing.assert_array_equal(Ie, I[sel])
+    np.testing.assert_array_equal(De.view(np.uint32), D[sel].view(np.uint32))
+    return len(sel)
+
+
 def test_config5_size_properties(oracle_mod):
     """BASELINE config 5 at its full single-GPU size (50M x 768 bf16 = 76.8 GB, top-100, 10k queries), where the oracle
     cannot follow: best-first order, reported scores equal to the canonical chain of rows regenerated on the CPU,
@@ -417,7 +438,9 @@ def test_config5_size_properties(oracle_mod):
     sub = [1, 4, 99, 2500, 7777, 9000, nq - 1]
     D7, I7 = idx.search(Q[sub], k)
     assert np.array_equal(I7, I[sub]) and np.array_equal(D7.view(np.uint32), D[sub].view(np.uint32))
-    print(f"config 5: scan {idx.last_scan_time()}")
+    scan = idx.last_scan_time()
+    ne = _exact_cross_check(idx, Q, D, I, k, len(planted))
+    print(f"config 5: scan {scan}; {ne} queries bit-equal on the exact path")
 
 
 def test_bench_size_properties(oracle_mod):
@@ -453,3 +476,5 @@ def test_bench_size_properties(oracle_mod):
     sub = [1, 4, 99, 2500, 7777, 9000, nq - 1]
     D7, I7 = idx.search(Q[sub], k)
     assert np.array_equal(I7, I[sub]) and np.array_equal(D7.view(np.uint32), D[sub].view(np.uint32))
+    ne = _exact_cross_check(idx, Q, D, I, k, len(planted))
+    print(f"config 4: {ne} queries bit-equal on the exact path")
