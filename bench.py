@@ -158,6 +158,40 @@ def bench_embed(args, dev, rank, world, barrier):
                          "tokens_per_s": round(float(plen.sum()) * args.embed_steps * world / el_p, 1),
                          "roofline": roof(flops(plen) * args.embed_steps, el_p)}
 
+    # ---- from STRINGS, what advanced_rag.py:295 passes: a local model directory (seeded weights + a synthetic WordPiece
+    # vocabulary, written here: nothing can be downloaded), B texts of ~1,700 characters that tokenise to 256 word pieces
+    # after truncation, through HuggingFaceEmbeddings.embed_documents_array (tokenise slab i + 1 on a worker thread while the
+    # GPU has slab i).  Rank 0 only: the tokenizer uses the host's cores, which the ranks of one box share.
+    if rank == 0 and B >= 256:
+        import shutil
+        import tempfile
+        from rag_amd.embeddings import MI355Embeddings
+        from rag_amd.encoder_weights import synthetic_texts, write_synthetic_model_dir
+        mdir = tempfile.mkdtemp(prefix="mi355rag_bench_model_")
+        try:
+            write_synthetic_model_dir(mdir, cfg, blob)
+            emb = MI355Embeddings(model_name=mdir, model_kwargs={"device": dev.index}, max_seq_length=L, slab_texts=1024)
+            texts = synthetic_texts(B, 215, cfg.vocab_size, seed=3)
+            emb.embed_documents_array(texts[:256])
+            t0 = time.perf_counter()
+            Et = emb.embed_documents_array(texts)
+            el_t = time.perf_counter() - t0
+            tm = dict(emb.last_timing)
+            t0 = time.perf_counter()
+            emb._tokenize_csr(texts[:1024])
+            tok_rate = 1024 / (time.perf_counter() - t0)
+            res["from_texts"] = {"value": round(B / el_t, 1), "unit": "chunks/s", "texts": B, "tokens": tm["tokens"],
+                                 "frac_of_via_api": round((B / el_t) / (chunks / el_api / world), 4),
+                                 "tokenize_s": round(tm["tokenize_s"], 3), "gpu_encode_s": round(tm["encode_s"], 3), "total_s": round(el_t, 3),
+                                 "tokenizer_texts_per_s": round(tok_rate, 1), "host_threads": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+                                 "bound": "host tokenizer" if tm["tokenize_s"] > tm["encode_s"] else "gpu",
+                                 "path": "List[str] -> tokenizers WordPiece (encode_batch_fast, all host cores) -> CSR -> mi_encoder_encode_ragged -> "
+                                         "fp32 rows; slabs of 1,024 texts, tokenising overlapped with the GPU",
+                                 "finite": bool(np.isfinite(Et).all())}
+            del emb
+        finally:
+            shutil.rmtree(mdir, ignore_errors=True)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
         ocfg = oracle.BertConfig(*[getattr(cfg, f) for f, _ in type(cfg)._fields_])
@@ -167,10 +201,96 @@ def bench_embed(args, dev, rank, world, barrier):
         tcpu = time.perf_counter() - tc
         Eg = E[:nb].cpu().numpy()
         cos = (Eg * Eo).sum(1) / (np.linalg.norm(Eg, axis=1) * np.linalg.norm(Eo, axis=1))
-        res["cpu_baseline"] = {"value": round(nb / tcpu, 3), "unit": "chunks/s", "cores": oracle.num_threads(), "kind": "port",
-                               "sample": f"oracle.encode (fp32 C port of BertModel + mean-pool) on {nb} of the same chunks in {tcpu:.1f}s"}
+        port = {"value": round(nb / tcpu, 3), "unit": "chunks/s", "cores": oracle.num_threads(), "kind": "port",
+                "sample": f"oracle.encode (fp32 C port of BertModel + mean-pool) on {nb} of the same chunks in {tcpu:.1f}s"}
+        legs = [port]
         res["parity_check"] = {"chunks": nb, "max_1_minus_cos_vs_oracle": float((1 - cos).max())}
+        # what sentence-transformers runs (requirements.txt:49 -> transformers BertModel on torch CPU, advanced_rag.py:106
+        # "device": "cpu") + its mean-pool / normalise, on the same chunks and weights, all host cores
+        try:
+            import transformers
+            from rag_amd.encoder_weights import unpack_blob
+            hc = transformers.BertConfig(vocab_size=cfg.vocab_size, hidden_size=H, num_hidden_layers=nl, num_attention_heads=cfg.num_attention_heads,
+                                         intermediate_size=I, max_position_embeddings=cfg.max_position_embeddings,
+                                         type_vocab_size=cfg.type_vocab_size, layer_norm_eps=cfg.layer_norm_eps, hidden_act="gelu")
+            model = transformers.BertModel(hc, add_pooling_layer=False).eval()
+            missing = model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in unpack_blob(cfg, blob).items()}, strict=False)
+            assert not missing.unexpected_keys and all("position_ids" in k for k in missing.missing_keys), missing
+            nt = 4 * oracle.num_threads()
+            ti, tmk = ids[:nt].cpu().long(), mask[:nt].cpu().long()
+            with torch.no_grad():
+                model(input_ids=ti[:2], attention_mask=tmk[:2])
+                tc = time.perf_counter()
+                hs = model(input_ids=ti, attention_mask=tmk).last_hidden_state
+                mk = tmk.unsqueeze(-1).float()
+                Et_ = torch.nn.functional.normalize((hs * mk).sum(1) / mk.sum(1).clamp(min=1e-9), dim=1)
+                ttorch = time.perf_counter() - tc
+            Eg2 = E[:nt].cpu().numpy()
+            cos2 = (Eg2 * Et_.numpy()).sum(1) / np.linalg.norm(Eg2, axis=1)
+            legs.append({"value": round(nt / ttorch, 3), "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "torch-bertmodel",
+                         "sample": f"transformers {transformers.__version__} BertModel (fp32, torch CPU) + mean-pool + normalise on {nt} of the same "
+                                   f"chunks in {ttorch:.1f}s", "max_1_minus_cos_gpu_vs_bertmodel": float((1 - cos2).max())})
+        except Exception as ex:          # noqa: BLE001  (transformers absent or incompatible: the port leg stands alone)
+            legs.append({"kind": "torch-bertmodel", "error": repr(ex)[:200]})
+        top = max([l for l in legs if "value" in l], key=lambda l: l["value"])
+        res["cpu_baseline"] = {"value": top["value"], "unit": "chunks/s", "cores": top["cores"], "kind": top["kind"],
+                               "sample": top["sample"], "legs": legs}
     return res
+
+
+def bench_configs(args, device, dev):
+    """The single-GPU BASELINE configs besides the headline, measured in the same driver run:
+      config2  1M x 384 fp32 corpus, 1k-query batch, exact top-10, IP on unit vectors (= cosine), MI_MODE_AUTO
+      config5  50M x 768 bf16 corpus, 10k-query batch, exact top-100 (the list a cross-encoder rerank batch is cut from)
+    wall = the whole mi_index_search_dev call (prep + scan + finish + certify + read-back of the certificate count),
+    scan = the dominant kernel alone (HIP events inside the library)."""
+    from rag_amd.index import FlatIndex
+    out = {}
+
+    def queries(n, d):
+        g = FlatIndex(d, metric="ip", dtype="f32", device=device)
+        g.add_synthetic(n, seed=1, normalize=True)
+        q = torch.from_numpy(g.reconstruct_n(0, n)).to(dev)
+        del g
+        return q
+
+    def run(name, n, d, dtype, nq, k, warm, steps, extra):
+        idx = FlatIndex(d, metric="ip", dtype=dtype, device=device)
+        idx.reserve(n)
+        idx.add_synthetic(n, seed=0, normalize=True)
+        q = queries(nq, d)
+        for _ in range(warm):
+            idx.search_torch(q, k)
+        st0 = idx.stats()
+        wall, scan = [], []
+        for _ in range(steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            idx.search_torch(q, k)
+            torch.cuda.synchronize()
+            wall.append((time.perf_counter() - t0) * 1e3)
+            scan.append(idx.last_scan_time()["ms"])
+        st1 = idx.stats()
+        w, sc = float(np.median(wall)), float(np.median(scan))
+        fl = 2.0 * nq * n * d
+        by = float(n) * d * (2 if dtype == "bf16" else 4)
+        res = {"workload": f"exact top-{k}, {n}x{d} {dtype} corpus, {nq}-query batch, IP on unit vectors (cosine), one GPU",
+               "wall_ms": round(w, 3), "scan_ms": round(sc, 3), "wall_over_scan": round(w / sc, 3), "queries_per_s": round(nq / (w * 1e-3), 1),
+               "scan_kernel": idx.last_scan_time()["kind"],
+               "roofline": {"bound": "mfma", "achieved": round(fl / (sc * 1e-3) / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(fl / (sc * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                            "floor_ms": {"hbm": round(by / (HBM_PEAK_GBS * 1e9) * 1e3, 3), "mfma": round(fl / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3, 3)},
+                            "traffic": pmc_traffic("scan", rows_per_gpu=n, dim=d, dtype=dtype, queries=nq)},
+               "queries_certified": st1["fast"] - st0["fast"], "queries_exact_rerun": st1["exact"] - st0["exact"], "steps": steps}
+        res.update(extra)
+        out[name] = res
+        del idx, q
+        torch.cuda.empty_cache()
+
+    run("config2", 1_000_000, 384, "f32", 1000, 10, 3, 7,
+        {"note": "fp32 index: the scan filters on a bf16 shadow of the rows, scores are the canonical fp32 chain of the fp32 rows"})
+    run("config5", 50_000_000, 768, "bf16", 10_000, 100, 1, 2, {})
+    return out
 
 
 def main() -> int:
@@ -192,6 +312,7 @@ def main() -> int:
     ap.add_argument("--embed-chunks", type=int, default=4096, help="256-token chunks per rank per embed step (0 = skip)")
     ap.add_argument("--embed-steps", type=int, default=3)
     ap.add_argument("--embed-only", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs 2 and 5 on this GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -295,6 +416,30 @@ def main() -> int:
                         "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "qps_per_gpu": round(Qs / (m * 1e-3), 1),
                         "algorithmic_GB": round(float(nloc) * d * (2 if args.dtype == "bf16" else 4) / 1e9, 2),
                         "traffic_GB": pmc_traffic("scan", rows_per_gpu=nloc, dim=d, dtype=args.dtype, queries=Qs)})
+    # ---- CPU sample rows (read back before the big index is released) and the live parity check: the CPU leg below computes
+    # oracle.search on the first `crow` rows x `cq` queries; a second index built from the same generator holds exactly those
+    # rows, the GPU answers the same queries on it and the two are compared bit for bit (ids and score bits).
+    cpu_rows = None
+    check_gpu = None
+    if rank == 0 and ngpu == 1 and not args.no_cpu_baseline:
+        crow = min(args.cpu_rows, nloc)
+        cq = min(args.cpu_queries, Q)
+        cpu_rows = idx.reconstruct_n(0, crow)            # the stored (bf16-rounded) values, as fp32
+        if args.check > 0:
+            sub = FlatIndex(d, metric="ip", dtype=args.dtype, device=local_rank)
+            sub.add_synthetic(crow, seed=0, normalize=True)
+            Ds, Is = sub.search_torch(q_dev[:cq].contiguous(), k)
+            check_gpu = (Ds.cpu().numpy(), Is.cpu().numpy(), sub.last_scan_time()["kind"], sub.stats())
+            del sub, Ds, Is
+
+    # ---- the other single-GPU BASELINE configs on the same device, after the headline index is released
+    configs = None
+    if rank == 0 and ngpu == 1 and not args.no_configs and (N, d, k, args.dtype) == (100_000_000, 384, 10, "bf16"):
+        del idx, D, I
+        torch.cuda.empty_cache()
+        configs = bench_configs(args, local_rank, dev)
+        idx = None
+
     embed = None
     if args.embed_chunks > 0:
         embed = bench_embed(args, dev, rank, world, barrier)
@@ -333,9 +478,7 @@ def main() -> int:
     check = None
     if not args.no_cpu_baseline and ngpu == 1:
         import oracle
-        crow = min(args.cpu_rows, nloc)
-        cq = min(args.cpu_queries, Q)
-        rows = idx.reconstruct_n(0, crow)            # the stored (bf16-rounded) values, as fp32
+        rows = cpu_rows
         odt = oracle.DTYPE_BF16 if args.dtype == "bf16" else oracle.DTYPE_F32
         rows_in = oracle.round_bf16(rows) if args.dtype == "bf16" else rows
         tc = time.perf_counter()
@@ -345,11 +488,13 @@ def main() -> int:
         port = {"value": cq / tcpu * (crow / float(N)), "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
                 "sample": f"oracle.search (AVX2 fmaf-chain port of IndexFlat) on the first {crow} rows x {cq} queries "
                           f"in {tcpu:.2f}s, extrapolated linearly in N to {N} rows"}
-        # parity spot check at bench size: the GPU answer restricted to the sample rows
-        if args.check > 0 and crow == nloc:
-            ok = bool(np.array_equal(I[:cq].cpu().numpy(), Io) and
-                      np.array_equal(D[:cq].cpu().numpy().view(np.uint32), Do.view(np.uint32)))
-            check = {"queries": cq, "bit_exact_vs_oracle": ok}
+        if check_gpu is not None:
+            Dg, Ig, gkind, gst = check_gpu
+            ok = bool(np.array_equal(Ig, Io) and np.array_equal(Dg.view(np.uint32), Do.view(np.uint32)))
+            check = {"queries": cq, "rows": crow, "k": k, "bit_exact_vs_oracle": ok, "gpu_scan_kernel": gkind,
+                     "queries_certified": gst["fast"], "queries_exact_rerun": gst["exact"],
+                     "what": "ids and score bits of the GPU answer on an index of the corpus' first rows (same generator) against "
+                             "oracle.search on those rows: the CPU leg's own result, so the check costs one small GPU search"}
         brow, bq = min(args.blas_rows, crow), min(args.blas_queries, Q)
         qb = np.ascontiguousarray(q_host[:bq])
         if args.dtype == "bf16":
@@ -378,7 +523,7 @@ def main() -> int:
                           f"(blocks of {blk} rows), extrapolated linearly in N to {N} rows",
                 "ids_equal_to_port": agree}
         top = blas if blas["value"] > port["value"] else port
-        cpu = {"value": top["value"], "unit": "queries/s", "cores": top["cores"], "kind": "port",
+        cpu = {"value": top["value"], "unit": "queries/s", "cores": top["cores"], "kind": top["kind"],
                "sample": top["sample"], "legs": [port, blas]}
 
     out = {
@@ -406,6 +551,8 @@ def main() -> int:
                                        "~6300 GB/s measured streaming ceiling (MI355X_MICROARCH.md)", "cases": regimes}
     if check is not None:
         out["parity_check"] = check
+    if configs is not None:
+        out["configs"] = configs
     if embed is not None:
         out["embed"] = embed
     print(json.dumps(out), flush=True)

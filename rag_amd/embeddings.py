@@ -210,7 +210,9 @@ class MI355Embeddings:
 
     # ---- tokenisation; the length-sorted batching of sentence-transformers' encode loop lives in the library
     def _tokenize(self, texts: List[str]):
-        return [e.ids for e in self.tokenizer.encode_batch(texts)]
+        # encode_batch_fast (tokenizers >= 0.20) skips the character-offset bookkeeping nobody reads here: 3x the rate
+        fn = getattr(self.tokenizer, "encode_batch_fast", None) or self.tokenizer.encode_batch
+        return [e.ids for e in fn(texts)]
 
     @staticmethod
     def _to_csr(toks) -> tuple:

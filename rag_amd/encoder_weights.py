@@ -139,3 +139,76 @@ def load_local_dir(path: str, normalize: bool = True, with_head: bool = False):
     if with_head:
         return cfg, pack_state_dict(sd, cfg), head_from_state_dict(sd, cfg)
     return cfg, pack_state_dict(sd, cfg)
+
+
+def unpack_blob(cfg: BertConfig, blob: np.ndarray) -> Dict[str, np.ndarray]:
+    """The inverse of pack_state_dict: flat fp32 blob -> transformers' BertModel parameter names."""
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    blob = np.asarray(blob, dtype=np.float32).reshape(-1)
+    pos = 0
+
+    def take(*shape):
+        nonlocal pos
+        n = int(np.prod(shape))
+        a = blob[pos:pos + n].reshape(shape)
+        pos += n
+        return a
+
+    sd = {"embeddings.word_embeddings.weight": take(cfg.vocab_size, H),
+          "embeddings.position_embeddings.weight": take(cfg.max_position_embeddings, H),
+          "embeddings.token_type_embeddings.weight": take(cfg.type_vocab_size, H),
+          "embeddings.LayerNorm.weight": take(H), "embeddings.LayerNorm.bias": take(H)}
+    for l in range(cfg.num_hidden_layers):
+        p = f"encoder.layer.{l}."
+        for nm, shp in [("attention.self.query", (H, H)), ("attention.self.key", (H, H)), ("attention.self.value", (H, H)),
+                        ("attention.output.dense", (H, H))]:
+            sd[p + nm + ".weight"] = take(*shp)
+            sd[p + nm + ".bias"] = take(shp[0])
+        sd[p + "attention.output.LayerNorm.weight"] = take(H)
+        sd[p + "attention.output.LayerNorm.bias"] = take(H)
+        sd[p + "intermediate.dense.weight"] = take(I, H)
+        sd[p + "intermediate.dense.bias"] = take(I)
+        sd[p + "output.dense.weight"] = take(H, I)
+        sd[p + "output.dense.bias"] = take(H)
+        sd[p + "output.LayerNorm.weight"] = take(H)
+        sd[p + "output.LayerNorm.bias"] = take(H)
+    if pos != blob.size:
+        raise ValueError(f"blob has {blob.size} elements, config needs {pos}")
+    return sd
+
+
+def synthetic_vocab(vocab_size: int):
+    """A WordPiece vocabulary of `vocab_size` entries for benches and tests (no vocabulary file exists offline): the five
+    BERT specials, whole words "w<n>" and continuation pieces "##x<n>", so "w17x4" tokenises to two pieces by the usual
+    greedy longest-prefix match."""
+    specials = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    n_words = (vocab_size - len(specials)) * 2 // 3
+    n_suffix = vocab_size - len(specials) - n_words
+    return specials + [f"w{i}" for i in range(n_words)] + [f"##x{i}" for i in range(n_suffix)], n_words, n_suffix
+
+
+def synthetic_texts(n: int, words_per_text: int, vocab_size: int, seed: int = 0, composite: float = 0.3):
+    """n strings over synthetic_vocab(vocab_size): `words_per_text` space-separated words, a fraction `composite` of them a
+    word + one continuation piece (two tokens)."""
+    _, n_words, n_suffix = synthetic_vocab(vocab_size)
+    rng = np.random.default_rng(seed)
+    w = rng.integers(0, n_words, size=(n, words_per_text))
+    sfx = rng.integers(0, n_suffix, size=(n, words_per_text))
+    comp = rng.random((n, words_per_text)) < composite
+    return [" ".join(f"w{a}x{b}" if c else f"w{a}" for a, b, c in zip(w[i], sfx[i], comp[i])) for i in range(n)]
+
+
+def write_synthetic_model_dir(path: str, cfg: BertConfig, blob: np.ndarray) -> str:
+    """A local model directory (config.json, vocab.txt, model.safetensors) for `cfg` with the weights of `blob` and
+    synthetic_vocab(cfg.vocab_size): what HuggingFaceEmbeddings(model_name=<dir>) loads, written without any download."""
+    from safetensors.numpy import save_file
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump({"vocab_size": cfg.vocab_size, "hidden_size": cfg.hidden_size, "num_hidden_layers": cfg.num_hidden_layers,
+                   "num_attention_heads": cfg.num_attention_heads, "intermediate_size": cfg.intermediate_size,
+                   "max_position_embeddings": cfg.max_position_embeddings, "type_vocab_size": cfg.type_vocab_size,
+                   "layer_norm_eps": cfg.layer_norm_eps, "hidden_act": "gelu"}, f)
+    with open(os.path.join(path, "vocab.txt"), "w") as f:
+        f.write("\n".join(synthetic_vocab(cfg.vocab_size)[0]) + "\n")
+    save_file({k: np.ascontiguousarray(v) for k, v in unpack_blob(cfg, blob).items()}, os.path.join(path, "model.safetensors"))
+    return path
