@@ -16,14 +16,19 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "..", "build", "obj")
 LIB = os.path.join(LIBDIR, "libmi355rag.so")
 
-SOURCES = ["capi.hip", "multi.hip", "ingest.hip", "search_exact.hip", "search_mfma.hip", "encoder.hip"]
-HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "mi355rag.h")]
+SOURCES = ["capi.hip", "multi.hip", "ingest.hip", "search_exact.hip", "search_mfma.hip", "encoder.hip", "encoder_ffn3.hip"]
+HEADERS = ["common.h", "kernels.h", "encoder_ffn3.h", os.path.join("..", "..", "include", "mi355rag.h")]
 
 # -ffp-contract=off: the canonical score is an explicit fmaf chain; nothing else may be fused.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
          # the SGPR-base LDS-DMA helpers write M0 inside their asm and list it as clobbered (it is a reserved register)
          "-Wno-inline-asm"]
+
+
+# encoder_ffn3.hip names its accumulator tile a[0:191] literally in inline asm: hipcc must not park spilled vector
+# registers in accumulator registers of its own choosing (it has none left to choose: see the kernel's header)
+FILE_FLAGS = {"encoder_ffn3.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
 
 
 def _stale(target: str, deps: list[str]) -> bool:
@@ -45,7 +50,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *FILE_FLAGS.get(src, []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -34,6 +34,7 @@
 #include <new>
 #include <vector>
 #include "kernels.h"
+#include "encoder_ffn3.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1957,6 +1958,10 @@ struct LayerW {
     uint16_t *Wi_p = nullptr;                      // [I / 32][12][32][32] swizzled LDS image of Wi blocks (ffn_ln_kernel)
     uint16_t *Wo_p = nullptr, *Wd_p = nullptr;     // the same, [in / 32][out][32]: a 32-k stage of gemm_ln_kernel is one contiguous block
     float *bqkv, *bo, *bi, *bd, *g1, *b1, *g2, *b2; // fp32
+    // ffn3_kernel (encoder_ffn3.hip): Wo, Wi, Wd as ONE stream of 108 fragment blocks in consumption order, and the layer's
+    // biases / LayerNorm parameters as one block (hidden 384, intermediate 1536 only; nullptr otherwise)
+    void* w3 = nullptr;
+    float* p3 = nullptr;
 };
 
 // grow-only pinned host block
@@ -2021,7 +2026,7 @@ extern "C" int64_t mi_encoder_blob_elems(const mi_bert_config* c)
 static void encoder_free(mi_encoder* e)
 {
     if (!e) return;
-    for (LayerW& lw : e->layers) if (lw.bqkv) (void)hipFree(lw.bqkv);
+    for (LayerW& lw : e->layers) { if (lw.bqkv) (void)hipFree(lw.bqkv); if (lw.w3) (void)hipFree(lw.w3); if (lw.p3) (void)hipFree(lw.p3); }
     if (e->blob) (void)hipFree(e->blob);
     if (e->wbf) (void)hipFree(e->wbf);
     if (e->ws) (void)hipFree(e->ws);
@@ -2105,6 +2110,13 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
         lw.bo = bo; lw.bi = bi; lw.bd = bd; lw.g1 = g1; lw.b1 = b1; lw.g2 = g2; lw.b2 = b2;
         e->layers.push_back(lw);                       // owned by e from here on (encoder_free releases bqkv)
         ENC_HIP(me);
+        if (H == 384 && I == 1536) {
+            LayerW& L = e->layers.back();
+            ENC_HIP(hipMalloc(&L.w3, mi_ffn3_stream_bytes()));
+            ENC_HIP(hipMalloc((void**)&L.p3, mi_ffn3_param_floats() * sizeof(float)));
+            const int prc = mi_ffn3_pack(e->stream, Wo, Wi, Wd, L.w3, bo, g1, b1, bi, bd, g2, b2, L.p3);
+            if (prc != MI_OK) return fail(prc);
+        }
         scale_f32_kernel<<<(unsigned)((H + 255) / 256), 256, 0, e->stream>>>(bq, lw.bqkv, H, qscale);
         ENC_HIP(hipMemcpyAsync(lw.bqkv + H, bk, (size_t)H * 4, hipMemcpyDeviceToDevice, e->stream));
         ENC_HIP(hipMemcpyAsync(lw.bqkv + 2 * H, bv, (size_t)H * 4, hipMemcpyDeviceToDevice, e->stream));
@@ -2380,12 +2392,18 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     const bool fused_front = fused_ffn && !front_off;
     // MI_FFN2=0: the first form of the fused FFN (ffn_ln_kernel) instead of the K-split one (ffn2_kernel); read per call (A/B)
     const bool ffn2 = !(getenv("MI_FFN2") && atoi(getenv("MI_FFN2")) == 0);
+    // MI_FFN3=0: the round-2 kernel (ffn2_kernel) instead of the token-on-the-lane one (encoder_ffn3.hip); read per call (A/B)
+    const bool ffn3 = fused_front && !(getenv("MI_FFN3") && atoi(getenv("MI_FFN3")) == 0);
     if (!capturing) MI_HIP(hipEventRecord(e->ev0, st));
     if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, types, pos_ids, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, types, pos_ids, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     for (const LayerW& lw : e->layers) {
         const bool qkv_blocked = launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H, true);
         attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, seq_start, ctx, L, Lp, H, qkv_blocked ? 1 : 0, fused_ln ? 1 : 0);
+        if (ffn3 && lw.w3) {
+            MI_TRY(mi_launch_ffn3(st, ctx, h, lw.w3, lw.p3, c.layer_norm_eps, h, (int)T));
+            continue;
+        }
         if (fused_front && ffn2) {
             ffn2_kernel<true><<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T,
                                                                            ctx, lw.Wo_p, lw.bo, lw.g1, lw.b1);

@@ -9,7 +9,7 @@ FILE=${FILE:-search_mfma}
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function -Wno-inline-asm"
 /opt/rocm/bin/hipcc $F $2 -c rag_amd/csrc/$FILE.hip -o tools/_ab/$1_$FILE.o
 OBJS=""
-for o in capi multi ingest search_exact search_mfma encoder; do
+for o in capi multi ingest search_exact search_mfma encoder encoder_ffn3; do
   if [ "$o" == "$FILE" ]; then OBJS="$OBJS tools/_ab/$1_$FILE.o"; else OBJS="$OBJS build/obj/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_ab/$1.so $OBJS
