@@ -38,6 +38,42 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def audit_ffn3(workdir: str | None = None, extra_flags=()) -> None:
+    """encoder_ffn3.hip keeps its output tile in accumulator registers a[0:191] that its inline asm names literally; that is
+    sound only while hipcc itself touches no accumulator register and spills nothing.  Compiles the file to assembly with
+    the library's flags and raises if the kernel breaks that contract (the first build of the kernel faulted on the GPU:
+    hipcc had parked LDS addresses in a0, a1, ...)."""
+    import re
+    import tempfile
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    with tempfile.TemporaryDirectory(dir=workdir) as td:
+        out = os.path.join(td, "ffn3.s")
+        subprocess.check_call([hipcc, *FLAGS, *FILE_FLAGS["encoder_ffn3.hip"], *extra_flags, "-S", "--cuda-device-only",
+                               os.path.join(CSRC, "encoder_ffn3.hip"), "-o", out], stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    body = text[text.index("_Z11ffn3_kernel"):]
+    inside, bad = False, []
+    for ln in body.splitlines():
+        if "#ASMSTART" in ln:
+            inside = True
+        elif "#ASMEND" in ln:
+            inside = False
+        elif not inside and (re.search(r"\bv_accvgpr", ln) or re.search(r"\ba\[?\d", ln.split(";")[0])):
+            bad.append(ln.strip())
+    if bad:
+        raise RuntimeError(f"encoder_ffn3.hip: hipcc uses accumulator registers of its own ({len(bad)} instructions, e.g. {bad[:3]})")
+    kd = body[body.index(".amdhsa_kernel"):]
+    if int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", kd).group(1)) != 0 or "scratch_" in body:
+        raise RuntimeError("encoder_ffn3.hip: the kernel uses scratch memory")
+    accum = int(re.search(r"\.amdhsa_accum_offset (\d+)", kd).group(1))
+    nfree = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", kd).group(1))
+    if nfree - accum < 192 or nfree > 512:
+        raise RuntimeError(f"encoder_ffn3.hip: accumulator allocation {accum}..{nfree} does not hold a[0:191]")
+    spills = re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)
+    if not spills or any(int(x) for x in spills):
+        raise RuntimeError(f"encoder_ffn3.hip: vector register spills {spills}")
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -60,6 +96,12 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:
             list(ex.map(run, jobs))
+        if any("encoder_ffn3.hip" in " ".join(j) for j in jobs):
+            try:
+                audit_ffn3()
+            except Exception:
+                os.remove(os.path.join(OBJDIR, "encoder_ffn3.o"))      # never link a build that breaks the contract
+                raise
     if jobs or force or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
     return LIB
