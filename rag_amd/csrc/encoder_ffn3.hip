@@ -143,6 +143,16 @@ __device__ __forceinline__ uint32_t f3_pack2(float lo, float hi)
 __device__ __forceinline__ float f3_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float f3_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
 
+// lanes l < 32 give y and take the upper lane's x; lanes l >= 32 give x and take the lower lane's y  (v_permlane32_swap_b32:
+// x[32 + r] <-> y[r]).  The two lanes of a token hold channels 4 h .. 4 h + 3 of every 8: two swaps turn a lane's two
+// 8-byte quads into one 16-byte run of 8 channels (and back), so rows move as dwordx4.
+__device__ __forceinline__ void f3_swap(uint32_t& x, uint32_t& y)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
+
 // erf-GELU as in encoder.hip (gelu_erf2): max(x, 0) - |x| / 2 * erfc(|x| / sqrt 2), erfc(z) ~= 2^(-z q(z)), one v_exp per value.
 // Written one value per instruction: beside MFMAs the packed-fp32 forms cost more than two plain ones
 // (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
@@ -347,23 +357,40 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
         F3_STAMP(0);
         bf16x8 cf[24];                                             // ctx^T, later h1^T: B fragments, k-step s (16 channels)
         // ---- token loads: ctx (blocked [tile][12][128][32]: two k-steps are one 64-B row of a block) and the residual row;
-        // the accumulators start at bo + h
+        // the accumulators start at bo + h.  A lane loads 8 consecutive channels of its token (channels 16 s + 8 h ..); the
+        // swap hands each lane of the pair its 4 + 4.  The parameter reads run one step ahead of their use (pr[]): a lone
+        // wave that reads LDS and waits, 48 times, pays the LDS latency 48 times.
         {
             const int tl = 32 * wave + r;                          // token within the tile (ctx is padded to whole tiles)
-#pragma unroll
-            for (int s = 0; s < 24; ++s)
-                cf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ctx + (((size_t)tile * 12 + (s >> 1)) * 128 + tl) * 32 + 16 * (s & 1) + 8 * h));
             int tok = m0 + r; if (tok > M - 1) tok = M - 1;
-            const uint16_t* const hrow = hin + (size_t)tok * F3_H + 4 * h;
-            static_for<2>([&](auto Gc) {                           // 24 requests at a time (48 registers beside the 96 of ctx^T)
-                constexpr int I0 = 24 * decltype(Gc)::value;
-                uint2 hv[24];
+            const uint16_t* const hrow = hin + (size_t)tok * F3_H + 8 * h;
+            f32x4 pr[2][2];
+            auto ld = [&](auto Sc) __attribute__((always_inline)) {
+                constexpr int s = decltype(Sc)::value;
+                pr[s & 1][0] = f3_ld4(p_bo + 16 * s);
+                pr[s & 1][1] = f3_ld4(p_bo + 16 * s + 8);
+            };
+            static_for<2>([&](auto Gc) {                           // 12 requests at a time (48 registers beside the 96 of ctx^T)
+                constexpr int S0 = 12 * decltype(Gc)::value;
+                uint4 hv[12];
 #pragma unroll
-                for (int i = 0; i < 24; ++i) hv[i] = *reinterpret_cast<const uint2*>(hrow + 32 * ((I0 + i) >> 2) + 8 * ((I0 + i) & 3));
-                static_for<24>([&](auto Ic) {
-                    constexpr int i = decltype(Ic)::value, T = (I0 + i) >> 2, Q = (I0 + i) & 3;
-                    const f32x4 bv = f3_ld4(p_bo + 32 * T + 8 * Q);
-                    f3_acc_write<T, Q>(f32x4{bv.x + f3_lo(hv[i].x), bv.y + f3_hi(hv[i].x), bv.z + f3_lo(hv[i].y), bv.w + f3_hi(hv[i].y)});
+                for (int i = 0; i < 12; ++i) hv[i] = *reinterpret_cast<const uint4*>(hrow + 16 * (S0 + i));
+                if constexpr (S0 == 0) {
+#pragma unroll
+                    for (int s = 0; s < 24; ++s)
+                        cf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ctx + (((size_t)tile * 12 + (s >> 1)) * 128 + tl) * 32 + 16 * (s & 1) + 8 * h));
+                    ld(IC<0>{});
+                }
+                static_for<12>([&](auto Ic) {
+                    constexpr int i = decltype(Ic)::value, s = S0 + i, T = s >> 1, Q = 2 * (s & 1);
+                    if constexpr (s + 1 < 24) ld(IC<s + 1>{});
+                    uint4 v = hv[i];
+                    f3_swap(v.x, v.z);
+                    f3_swap(v.y, v.w);
+                    const f32x4 b0 = pr[s & 1][0], b1 = pr[s & 1][1];
+                    f3_acc_write<T, Q>(f32x4{b0.x + f3_lo(v.x), b0.y + f3_hi(v.x), b0.z + f3_lo(v.y), b0.w + f3_hi(v.y)});
+                    f3_acc_write<T, Q + 1>(f32x4{b1.x + f3_lo(v.z), b1.y + f3_hi(v.z), b1.z + f3_lo(v.w), b1.w + f3_hi(v.w)});
+                    __builtin_amdgcn_sched_barrier(0);
                 });
             });
         }
@@ -388,34 +415,49 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
         F3_STAMP(2);
 
         // ---- LayerNorm 1 in registers; h1 (bf16) becomes the B fragments of FFN1 and the residual of LayerNorm 2.
-        {
-            // one pass over the accumulator registers for the statistics, shifted by the token's first channel (the two lanes
-            // of a token share it) so that E[d^2] - E[d]^2 does not cancel; a second pass normalises
+        // One pass over the accumulator registers for the statistics, shifted by the token's first channel (the two lanes of a
+        // token share it) so that E[d^2] - E[d]^2 does not cancel; a second pass normalises, two quads (one k-step of FFN1)
+        // per step, with the step's twelve parameter quads requested a step ahead.
+        auto row_stats = [&](float& scale, float& shift) __attribute__((always_inline)) {
             const f32x4 first = f3_acc_read<0, 0>();
             const float K = __shfl(first[0], r, 64);
+            const f32x4 nK = {-K, -K, -K, -K};
             f32x4 sv = {0.0f, 0.0f, 0.0f, 0.0f}, qv = {0.0f, 0.0f, 0.0f, 0.0f};
             static_for<48>([&](auto Ic) {
-                const f32x4 d = f3_acc_read<decltype(Ic)::value / 4, decltype(Ic)::value % 4>() - K;
+                const f32x4 d = f3_acc_read<decltype(Ic)::value / 4, decltype(Ic)::value % 4>() + nK;
                 sv += d;
                 qv = __builtin_elementwise_fma(d, d, qv);
             });
             const float m1 = f3_pair_sum((sv[0] + sv[1]) + (sv[2] + sv[3])) * (1.0f / F3_H);
-            const float mean = K + m1;
             const float var = fmaxf(__builtin_fmaf(-m1, m1, f3_pair_sum((qv[0] + qv[1]) + (qv[2] + qv[3])) * (1.0f / F3_H)), 0.0f);
-            const float inv = 1.0f / sqrtf(var + eps);
+            scale = 1.0f / sqrtf(var + eps);
+            shift = -(K + m1) * scale;                             // (x - mean) / sd as one multiply-add
+        };
+        {
+            float inv, nm;
+            row_stats(inv, nm);
+            const f32x4 inv4 = {inv, inv, inv, inv}, nm4 = {nm, nm, nm, nm};
+            f32x4 pr[2][6];
+            auto ld = [&](auto Sc) __attribute__((always_inline)) {
+                constexpr int s = decltype(Sc)::value;
+                pr[s & 1][0] = f3_ld4(p_g1 + 16 * s);  pr[s & 1][1] = f3_ld4(p_g1 + 16 * s + 8);
+                pr[s & 1][2] = f3_ld4(p_be1 + 16 * s); pr[s & 1][3] = f3_ld4(p_be1 + 16 * s + 8);
+                pr[s & 1][4] = f3_ld4(p_b2 + 16 * s);  pr[s & 1][5] = f3_ld4(p_b2 + 16 * s + 8);
+            };
+            ld(IC<0>{});
             static_for<24>([&](auto Sc) {                          // k-step s = registers 8 (s & 1) .. of tile s >> 1
-                constexpr int s = decltype(Sc)::value, T = s >> 1;
-                uint32_t w[4];
-                static_for<2>([&](auto Hc) {
-                    constexpr int hh = decltype(Hc)::value, Q = 2 * (s & 1) + hh;
-                    const f32x4 y = __builtin_elementwise_fma((f3_acc_read<T, Q>() - mean) * inv, f3_ld4(p_g1 + 32 * T + 8 * Q), f3_ld4(p_be1 + 32 * T + 8 * Q));
-                    w[2 * hh] = f3_pack2(y[0], y[1]);
-                    w[2 * hh + 1] = f3_pack2(y[2], y[3]);
-                    // the second product accumulates onto b2 + h1 (the bf16 values the next layer would read)
-                    const f32x4 b2v = f3_ld4(p_b2 + 32 * T + 8 * Q);
-                    f3_acc_write<T, Q>(f32x4{b2v.x + f3_lo(w[2 * hh]), b2v.y + f3_hi(w[2 * hh]), b2v.z + f3_lo(w[2 * hh + 1]), b2v.w + f3_hi(w[2 * hh + 1])});
-                });
-                cf[s] = __builtin_bit_cast(bf16x8, uint4{w[0], w[1], w[2], w[3]});
+                constexpr int s = decltype(Sc)::value, T = s >> 1, Q = 2 * (s & 1);
+                if constexpr (s + 1 < 24) ld(IC<s + 1>{});
+                const f32x4 y0 = __builtin_elementwise_fma(__builtin_elementwise_fma(f3_acc_read<T, Q>(), inv4, nm4), pr[s & 1][0], pr[s & 1][2]);
+                const f32x4 y1 = __builtin_elementwise_fma(__builtin_elementwise_fma(f3_acc_read<T, Q + 1>(), inv4, nm4), pr[s & 1][1], pr[s & 1][3]);
+                uint32_t w0 = f3_pack2(y0[0], y0[1]), w1 = f3_pack2(y0[2], y0[3]), w2 = f3_pack2(y1[0], y1[1]), w3 = f3_pack2(y1[2], y1[3]);
+                asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));     // (or hipcc converts every low half a second time)
+                // the second product accumulates onto b2 + h1 (the bf16 values the next layer would read)
+                const f32x4 c0 = pr[s & 1][4], c1 = pr[s & 1][5];
+                f3_acc_write<T, Q>(f32x4{c0.x + f3_lo(w0), c0.y + f3_hi(w0), c0.z + f3_lo(w1), c0.w + f3_hi(w1)});
+                f3_acc_write<T, Q + 1>(f32x4{c1.x + f3_lo(w2), c1.y + f3_hi(w2), c1.z + f3_lo(w3), c1.w + f3_hi(w3)});
+                cf[s] = __builtin_bit_cast(bf16x8, uint4{w0, w1, w2, w3});
+                __builtin_amdgcn_sched_barrier(0);
             });
         }
         F3_ACC_SETTLE();
@@ -551,31 +593,34 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
         F3_ACC_SETTLE();
         F3_STAMP(4);
 
-        // ---- LayerNorm 2 and the row out (8 bytes per lane and channel group)
+        // ---- LayerNorm 2 and the row out: 16 bytes per lane and k-step (the swap of the loads, backwards), 32 contiguous
+        // bytes per row and instruction
         {
-            // one pass over the accumulator registers for the statistics, shifted by the token's first channel (the two lanes
-            // of a token share it) so that E[d^2] - E[d]^2 does not cancel; a second pass normalises
-            const f32x4 first = f3_acc_read<0, 0>();
-            const float K = __shfl(first[0], r, 64);
-            f32x4 sv = {0.0f, 0.0f, 0.0f, 0.0f}, qv = {0.0f, 0.0f, 0.0f, 0.0f};
-            static_for<48>([&](auto Ic) {
-                const f32x4 d = f3_acc_read<decltype(Ic)::value / 4, decltype(Ic)::value % 4>() - K;
-                sv += d;
-                qv = __builtin_elementwise_fma(d, d, qv);
-            });
-            const float m1 = f3_pair_sum((sv[0] + sv[1]) + (sv[2] + sv[3])) * (1.0f / F3_H);
-            const float mean = K + m1;
-            const float var = fmaxf(__builtin_fmaf(-m1, m1, f3_pair_sum((qv[0] + qv[1]) + (qv[2] + qv[3])) * (1.0f / F3_H)), 0.0f);
-            const float inv = 1.0f / sqrtf(var + eps);
+            float inv, nm;
+            row_stats(inv, nm);
+            const f32x4 inv4 = {inv, inv, inv, inv}, nm4 = {nm, nm, nm, nm};
             // rows past the last token are computed like the others (a column of the tile never mixes with another); their
-            // lanes are switched off for the stores, once, here
+            // lanes are switched off, once, here -- both lanes of a token or neither, so the swaps stay among active pairs
             const int tok = m0 + r;
             if (tok < M) {
-                uint16_t* const orow = hout + (size_t)tok * F3_H + 4 * h;
-                static_for<48>([&](auto Ic) {
-                    constexpr int i = decltype(Ic)::value;
-                    const f32x4 y = __builtin_elementwise_fma((f3_acc_read<i / 4, i % 4>() - mean) * inv, f3_ld4(p_g2 + 32 * (i >> 2) + 8 * (i & 3)), f3_ld4(p_be2 + 32 * (i >> 2) + 8 * (i & 3)));
-                    *reinterpret_cast<uint2*>(orow + 32 * (i >> 2) + 8 * (i & 3)) = make_uint2(f3_pack2(y[0], y[1]), f3_pack2(y[2], y[3]));
+                uint16_t* const orow = hout + (size_t)tok * F3_H + 8 * h;
+                f32x4 pr[2][4];
+                auto ld = [&](auto Sc) __attribute__((always_inline)) {
+                    constexpr int s = decltype(Sc)::value;
+                    pr[s & 1][0] = f3_ld4(p_g2 + 16 * s);  pr[s & 1][1] = f3_ld4(p_g2 + 16 * s + 8);
+                    pr[s & 1][2] = f3_ld4(p_be2 + 16 * s); pr[s & 1][3] = f3_ld4(p_be2 + 16 * s + 8);
+                };
+                ld(IC<0>{});
+                static_for<24>([&](auto Sc) {
+                    constexpr int s = decltype(Sc)::value, T = s >> 1, Q = 2 * (s & 1);
+                    if constexpr (s + 1 < 24) ld(IC<s + 1>{});
+                    const f32x4 y0 = __builtin_elementwise_fma(__builtin_elementwise_fma(f3_acc_read<T, Q>(), inv4, nm4), pr[s & 1][0], pr[s & 1][2]);
+                    const f32x4 y1 = __builtin_elementwise_fma(__builtin_elementwise_fma(f3_acc_read<T, Q + 1>(), inv4, nm4), pr[s & 1][1], pr[s & 1][3]);
+                    uint32_t w0 = f3_pack2(y0[0], y0[1]), w1 = f3_pack2(y0[2], y0[3]), w2 = f3_pack2(y1[0], y1[1]), w3 = f3_pack2(y1[2], y1[3]);
+                    f3_swap(w0, w2);
+                    f3_swap(w1, w3);
+                    *reinterpret_cast<uint4*>(orow + 16 * s) = uint4{w0, w1, w2, w3};
+                    __builtin_amdgcn_sched_barrier(0);
                 });
             }
         }
