@@ -47,7 +47,16 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 #define F3_H 384
 #define F3_I 1536
 #define F3_BLK 24576                          // one weight block: 24 fragments x 1 KB
-#define F3_SLOTS 5                            // the ring stays below 128 KB: no LDS-DMA destination with bit 17 set (M0)
+#ifndef F3_BAR2
+#define F3_BAR2 1                             // 1: one barrier per TWO blocks (six slots, four blocks ahead); 0: one per block (5, 3)
+#endif
+#if F3_BAR2
+#define F3_SLOTS 6
+#define F3_AHEAD 4                            // block b + 4 is requested while block b is consumed (into the slot of block b - 2)
+#else
+#define F3_SLOTS 5
+#define F3_AHEAD 3
+#endif
 #define F3_RING (F3_SLOTS * F3_BLK)
 #define F3_NFRONT 12
 #define F3_NBLK (F3_NFRONT + 2 * (F3_I / 32)) // 108 blocks per tile
@@ -64,10 +73,8 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 #define F3_RA 3                               // fragments requested from LDS ahead of the one being multiplied
 #endif
 #define F3_PIECES_EARLY ((24 - F3_RA + 2) / 4) // pieces a block requests (steps 1, 5, ...) before the barrier at step 24 - F3_RA
-#define F3_AHEAD 3                            // block b + 3 is requested while block b is consumed (into the slot of block b - 2)
 
 static_assert(F3_LDS_BYTES <= 160 * 1024, "LDS");
-static_assert(F3_RING <= 128 * 1024, "LDS-DMA destinations stay below 128 KB");
 static_assert(F3_AHEAD + 2 == F3_SLOTS, "block b + AHEAD reuses the slot of block b - 2");
 
 size_t mi_ffn3_stream_bytes() { return (size_t)F3_NBLK * F3_BLK; }
@@ -297,14 +304,19 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
     // before).  The requests never stop -- past the workgroup's last block they fetch the stream's next blocks into slots
     // nobody reads again (72 KB of L2 reads per workgroup) -- so the count in flight is the same at every block and the
     // loop has no branch; the kernel's last instruction drains them.
-    // Slot reuse: a piece requested after the barrier inside block b - 1 overwrites block b - 2's slot (or b - 3's), and every
-    // wave that passed that barrier has consumed all of block b - 2 in MFMAs.
+    // With F3_BAR2 only the odd blocks carry the barrier, and it covers the next TWO blocks (four waves in lockstep on one LDS
+    // cost ~100 cycles per barrier: stamps with the barrier ablated).
+    // Slot reuse: a piece requested in block b overwrites the slot of block b - 2.  Every wave has passed the barrier inside
+    // block b - 1 (or b - 2, F3_BAR2 and b odd -- then it has at least ISSUED its last LDS read of block b - 2, at step
+    // 23 - F3_RA, before the barrier, a block and more before the request, and the LDS serves its queue in order).
     bf16x8 nx[F3_RA];                                              // fragments 0 .. F3_RA - 1 of the next block
-    auto next_block_barrier = [&](int in_flight) __attribute__((always_inline)) {
+    auto next_block_barrier = [&](auto Startc) __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
 #ifndef F3_ABL_DMA
-        if (in_flight == 6 * (F3_AHEAD - 1)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * (F3_AHEAD - 1)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * (F3_AHEAD - 2) + F3_PIECES_EARLY) : "memory");
+        // in flight behind the pieces waited for: at the start, the prologue's later blocks; in a block, the blocks requested
+        // since plus this block's early pieces
+        constexpr int later = decltype(Startc)::value ? 6 * (F3_AHEAD - 1 - F3_BAR2) : 6 * (F3_AHEAD - 2 - F3_BAR2) + F3_PIECES_EARLY;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(later) : "memory");
 #endif
 #ifndef F3_ABL_BARRIER
         asm volatile("s_barrier" ::: "memory");
@@ -319,9 +331,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
     };
     // one step of a block: LDS read-ahead (this block's fragment f + F3_RA, or the next block's first ones behind the barrier)
     // into a[] / nx[]; the caller's MFMA and fillers follow
-    auto step_reads = [&](bf16x8 (&a)[24], const char* slot, const char* nslot, auto Fc) __attribute__((always_inline)) {
+    auto step_reads = [&](bf16x8 (&a)[24], const char* slot, const char* nslot, auto Fc, auto Oddc) __attribute__((always_inline)) {
         constexpr int f = decltype(Fc)::value;
-        if constexpr (f == 24 - F3_RA) next_block_barrier(0);
+        if constexpr (f == 24 - F3_RA && (!F3_BAR2 || decltype(Oddc)::value)) next_block_barrier(IC<0>{});
         if constexpr (f + F3_RA < 24) a[f + F3_RA] = *reinterpret_cast<const bf16x8*>(slot + (f + F3_RA) * 1024);
         else nx[f + F3_RA - 24] = *reinterpret_cast<const bf16x8*>(nslot + (f + F3_RA - 24) * 1024);
     };
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
         request_done();
     }
     __syncthreads();
-    next_block_barrier(6 * (F3_AHEAD - 1));                        // block 0 has landed
+    next_block_barrier(IC<1>{});                                   // block 0 (and block 1) landed
 #pragma unroll
     for (int f = 0; f < F3_RA; ++f) nx[f] = *reinterpret_cast<const bf16x8*>(lds + lane * 16 + f * 1024);
     // one lane base for every parameter read (channels 4 h .. of an 8-channel group), the rest in the instructions' offsets;
@@ -404,7 +416,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
             BLOCK_OPEN();
             static_for<24>([&](auto Fc) {
                 constexpr int f = decltype(Fc)::value;
-                step_reads(a, slot, nslot, Fc);
+                step_reads(a, slot, nslot, Fc, IC<(b & 1)>{});
                 f3_mfma_acc<f % 12>(a[f], cf[2 * b + f / 12]);
                 step_request(Fc);
                 __builtin_amdgcn_sched_barrier(0);
@@ -548,11 +560,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
             }
         };
         // FFN1 of block j onto Xd (= b1 + W1_j h1^T); GELU share of Xg alongside
-        auto ffn1 = [&](int j, f32x16& Xd, const f32x16& Xg, auto K0c, auto NVc) __attribute__((always_inline)) {
+        auto ffn1 = [&](int j, f32x16& Xd, const f32x16& Xg, auto K0c, auto NVc, auto Oddc) __attribute__((always_inline)) {
             BLOCK_OPEN();
             static_for<24>([&](auto Fc) {
                 constexpr int f = decltype(Fc)::value;
-                step_reads(a, slot, nslot, Fc);
+                step_reads(a, slot, nslot, Fc, Oddc);
                 f3_mfma_x<f == 0>(Xd, a[f], cf[f]);
                 gelu_step(Xg, Fc, K0c, NVc);
                 step_request(Fc);
@@ -561,12 +573,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
             block_end();
         };
         // FFN2 of the block whose gelu is in G; GELU share of Xg alongside
-        auto ffn2 = [&](const f32x16& Xg, auto K0c, auto NVc, f32x16& Xn, int jn) __attribute__((always_inline)) {
+        auto ffn2 = [&](const f32x16& Xg, auto K0c, auto NVc, f32x16& Xn, int jn, auto Oddc) __attribute__((always_inline)) {
             BLOCK_OPEN();
             static_for<24>([&](auto Fc) {
                 constexpr int f = decltype(Fc)::value;
                 if constexpr (f == 4) { if (jn >= 0) load_bias(Xn, jn); }
-                step_reads(a, slot, nslot, Fc);
+                step_reads(a, slot, nslot, Fc, Oddc);
                 f3_mfma_acc<f / 2>(a[f], G[f & 1]);
                 gelu_step(Xg, Fc, K0c, NVc);
                 step_request(Fc);
@@ -576,20 +588,21 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
         };
         load_bias(Xa, 0);
         load_bias(Xb, 1);
-        ffn1(0, Xa, Xa, IC<0>{}, IC<0>{});                         // X_0
-        ffn1(1, Xb, Xa, IC<0>{}, IC<4>{});                         // X_1 beside the whole gelu of X_0
+        // (the last argument: the block's number within the tile is odd -- the blocks that carry the barrier when F3_BAR2)
+        ffn1(0, Xa, Xa, IC<0>{}, IC<0>{}, IC<0>{});                // X_0
+        ffn1(1, Xb, Xa, IC<0>{}, IC<4>{}, IC<1>{});                // X_1 beside the whole gelu of X_0
         gelu_finish();                                             // G = gelu(X_0)
         for (int j = 0; j < F3_I / 32 - 2; j += 2) {
-            ffn2(Xb, IC<0>{}, IC<2>{}, Xa, j + 2);                 // block j (G); first half of gelu(X_{j+1}); Xa = b1 of block j + 2
-            ffn1(j + 2, Xa, Xb, IC<2>{}, IC<2>{});                 // X_{j+2}; second half
+            ffn2(Xb, IC<0>{}, IC<2>{}, Xa, j + 2, IC<0>{});        // block j (G); first half of gelu(X_{j+1}); Xa = b1 of block j + 2
+            ffn1(j + 2, Xa, Xb, IC<2>{}, IC<2>{}, IC<1>{});        // X_{j+2}; second half
             gelu_finish();                                         // G = gelu(X_{j+1})
-            ffn2(Xa, IC<0>{}, IC<2>{}, Xb, j + 3);                 // block j + 1
-            ffn1(j + 3, Xb, Xa, IC<2>{}, IC<2>{});                 // X_{j+3}
+            ffn2(Xa, IC<0>{}, IC<2>{}, Xb, j + 3, IC<0>{});        // block j + 1
+            ffn1(j + 3, Xb, Xa, IC<2>{}, IC<2>{}, IC<1>{});        // X_{j+3}
             gelu_finish();                                         // G = gelu(X_{j+2})
         }
-        ffn2(Xb, IC<0>{}, IC<4>{}, Xa, -1);                        // block 46 beside the whole gelu of X_47
+        ffn2(Xb, IC<0>{}, IC<4>{}, Xa, -1, IC<0>{});               // block 46 beside the whole gelu of X_47
         gelu_finish();
-        ffn2(Xb, IC<0>{}, IC<0>{}, Xa, -1);                        // block 47
+        ffn2(Xb, IC<0>{}, IC<0>{}, Xa, -1, IC<1>{});               // block 47
         F3_ACC_SETTLE();
         F3_STAMP(4);
 
