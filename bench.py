@@ -34,10 +34,14 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def _sha256(path):
+def _sha256(paths):
+    """SHA-256 of one file, or of several concatenated in the order given."""
     import hashlib
-    with open(path, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()
+    h = hashlib.sha256()
+    for path in ([paths] if isinstance(paths, str) else paths):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def pmc_traffic(name, **case):
@@ -48,7 +52,8 @@ def pmc_traffic(name, **case):
         with open(os.path.join(ROOT, "profiles", "scan_traffic.json")) as f:
             doc = json.load(f)
         sec = doc[name]
-        if _sha256(os.path.join(ROOT, sec["kernel_source"])) != sec["kernel_source_sha256"]:
+        srcs = sec["kernel_source"]
+        if _sha256([os.path.join(ROOT, p) for p in ([srcs] if isinstance(srcs, str) else srcs)]) != sec["kernel_source_sha256"]:
             return None
         for c in sec["cases"]:
             if all(c.get(k) == v for k, v in case.items()):
@@ -108,7 +113,7 @@ def bench_embed(args, dev, rank, world, barrier):
     rl = roof(flops([L] * B) * args.embed_steps, el)
     rl.update({"traffic": pmc_traffic("encoder", chunks=B, tokens=L),
                "note": "whole encoder forward (all kernels), algorithmic 6.04 GFLOP per chunk; traffic = FETCH + WRITE bytes "
-                       "per 4096-chunk call from the committed PMC pass (GB), null when encoder.hip changed since"})
+                       "per 4096-chunk call from the committed PMC pass (GB), null when encoder.hip / encoder_ffn3.hip changed since"})
     res = {"metric": "chunks/s embed (256-token chunks, MiniLM-L6, bf16 MFMA)", "value": round(chunks / el, 1),
            "unit": "chunks/s", "chunks_per_step_per_gpu": B, "steps": args.embed_steps, "roofline": rl, "cpu_baseline": None}
 

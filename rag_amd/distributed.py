@@ -47,7 +47,7 @@ class ShardedFlatIndex:
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.d, self.metric, self.dtype = int(d), metric, dtype
+        self.d, self.metric, self.dtype = int(d), metric, str(dtype).lower()
         self.n_total = 0
         if local_index is None:
             from .index import FlatIndex
@@ -118,6 +118,8 @@ class ShardedFlatIndex:
         Dm = np.concatenate([g[r, :nq * k * 4].view(np.float32).reshape(nq, k) for r in range(self.world)], axis=1)
         Im = np.concatenate([g[r, off:off + nq * k * 8].view(np.int64).reshape(nq, k) for r in range(self.world)], axis=1)
         if self._merge is None:
+            if self.world == 1:
+                return Dn, In                      # one rank: the local lists are the answer
             raise RuntimeError("a host engine needs a merge_fn (the HIP merge runs on device tensors only)")
         D, I = self._merge(torch.from_numpy(Dm), torch.from_numpy(Im), k, self.metric)
         return D.numpy(), I.numpy()
@@ -134,7 +136,8 @@ class ShardedFlatIndex:
         n = self.local.ntotal
         lo = int(getattr(self.local, "id_base", None) if getattr(self.local, "id_base", None) is not None
                  else shard_range(self.n_total, self.world, self.rank)[0])
-        npdt = np.uint16 if self.dtype in ("bf16", "bfloat16") else np.float32
+        # the file holds what reconstruct_raw returns (bf16 bit patterns or fp32 rows): its dtype comes from the data
+        npdt = np.asarray(self.local.reconstruct_raw(0, min(n, 1))).dtype if n else (np.uint16 if self.dtype in ("bf16", "bfloat16") else np.float32)
         path = os.path.join(folder_path, f"{index_name}.shard{self.rank:03d}.rows.npy")
         mm = np.lib.format.open_memmap(path, mode="w+", dtype=npdt, shape=(n, self.d))
         slab = max(1, (256 << 20) // (self.d * 4))

@@ -171,25 +171,36 @@ def rerank_pairs(query: str, documents: Sequence[Document], tokenizer: Any, max_
     types = np.zeros((n, L), dtype=np.int32)
     mask = np.zeros((n, L), dtype=np.int32)
     for i, e in enumerate(encs):
-        m = min(len(e.ids), L)
-        ids[i, :m] = e.ids[:m]
-        types[i, :m] = e.type_ids[:m]
+        ei, et = _cut_pair(e.ids, e.type_ids, L)
+        m = len(ei)
+        ids[i, :m] = ei
+        types[i, :m] = et
         mask[i, :m] = 1
     return ids, types, mask
+
+
+def _cut_pair(ids, type_ids, max_length: int):
+    """A pair longer than max_length that the tokenizer did not truncate itself: cut the passage but keep the closing
+    token ([SEP]) and its segment id, as the tokenizer's own truncation does."""
+    if len(ids) <= max_length:
+        return list(ids), list(type_ids)
+    if max_length < 2:
+        return list(ids[:max_length]), list(type_ids[:max_length])
+    return list(ids[:max_length - 1]) + [ids[-1]], list(type_ids[:max_length - 1]) + [type_ids[-1]]
 
 
 def rerank_pairs_csr(pairs: Sequence[Sequence[str]], tokenizer: Any, max_length: int = 512):
     """(query, passage) pairs -> one flat int32 token array, its token types and offsets [n + 1] (no padding): the input
     of mi_encoder_classify_ragged.  Truncation to max_length is the tokenizer's (it keeps the closing [SEP]); a
-    tokenizer without truncation configured is cut here as rerank_pairs does."""
+    tokenizer without truncation configured is cut here, keeping the closing token too (_cut_pair)."""
     import numpy as np
     ids, types, offsets = [], [], [0]
     for q, passage in pairs:
         e = tokenizer.encode(q, passage)
-        m = min(len(e.ids), max_length)
-        ids.extend(e.ids[:m])
-        types.extend(e.type_ids[:m])
-        offsets.append(offsets[-1] + m)
+        ei, et = _cut_pair(e.ids, e.type_ids, max_length)
+        ids.extend(ei)
+        types.extend(et)
+        offsets.append(offsets[-1] + len(ei))
     return np.asarray(ids, dtype=np.int32), np.asarray(types, dtype=np.int32), np.asarray(offsets, dtype=np.int64)
 
 
@@ -202,7 +213,8 @@ class CrossEncoderReranker:
     One label: the score is the logit (`activation="sigmoid"` squashes it as CrossEncoder.predict does by default)."""
 
     def __init__(self, model_name: Optional[str] = None, device: int = 0, max_length: int = 512,
-                 encoder: Any = None, tokenizer: Any = None, activation: Optional[str] = None):
+                 encoder: Any = None, tokenizer: Any = None, activation: Optional[str] = None,
+                 score_label: Optional[int] = None):
         from .embeddings import Encoder, _load_tokenizer
         if encoder is None:
             from .encoder_weights import load_local_dir
@@ -212,6 +224,7 @@ class CrossEncoderReranker:
             max_length = min(max_length, int(cfg.max_position_embeddings))
             tokenizer = _load_tokenizer(model_name, max_length)
         self.encoder, self.tokenizer, self.max_length, self.activation = encoder, tokenizer, int(max_length), activation
+        self.score_label = score_label                  # column of a multi-label head that rank() orders by
 
     def predict(self, pairs: Sequence[Sequence[str]]):
         import numpy as np
@@ -244,5 +257,11 @@ class CrossEncoderReranker:
         if not docs:
             return []
         s = self.predict([(query, d.page_content) for d in docs])
+        if s.ndim > 1:
+            # a multi-label head has no single relevance score: the caller names the column (sentence-transformers'
+            # CrossEncoder.rank is defined for num_labels == 1 only)
+            if self.score_label is None:
+                raise ValueError(f"rank() needs one score per pair; the head has {s.shape[1]} labels: pass score_label=<column>")
+            s = s[:, int(self.score_label)]
         order = np.argsort(-s, kind="stable")
         return [docs[i] for i in (order if top_n is None else order[:top_n])]

@@ -136,3 +136,25 @@ def test_shard_ranges_partition_the_rows():
             r = [shard_range(n, world, i) for i in range(world)]
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+
+
+def test_world_of_one_host_path_and_dtype_spelling(tmp_path, oracle_mod):
+    """No process group, a host engine and no merge_fn: the local lists are the answer; dtype='BF16' (any case) saves bf16
+    bit patterns, not a numeric cast of them, and loads back to the same answer."""
+    from rag_amd.distributed import ShardedFlatIndex
+    from tests._fakes import OracleIndex
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((300, 24)).astype(np.float32)
+    Q = rng.standard_normal((4, 24)).astype(np.float32)
+    sh = ShardedFlatIndex(24, metric="ip", dtype="BF16", local_index=OracleIndex(24, "ip", "bf16"))
+    assert sh.dtype == "bf16"
+    sh.add_global(X)
+    D, I = sh.search(Q, 7)
+    Do, Io = oracle_mod.search(X, Q, 7, metric=oracle_mod.METRIC_IP, dtype=oracle_mod.DTYPE_BF16)
+    assert np.array_equal(I, Io) and np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    sh.save_local(str(tmp_path / "s"))
+    rows = np.load(str(tmp_path / "s" / "index.shard000.rows.npy"))
+    assert rows.dtype == np.uint16 and np.array_equal(rows, oracle_mod.round_bf16(X))
+    back = ShardedFlatIndex.load_local(str(tmp_path / "s"), local_index=OracleIndex(24, "ip", "bf16"))
+    D2, I2 = back.search(Q, 7)
+    assert np.array_equal(I2, Io) and np.array_equal(D2.view(np.uint32), Do.view(np.uint32))

@@ -175,3 +175,46 @@ def test_rerank_pair_assembly(tmp_path):
     assert ids[0].tolist() == [2, 13, 9, 3, 5, 6, 7, 3]                       # [CLS] q [SEP] passage [SEP]
     assert types[0].tolist() == [0, 0, 0, 0, 1, 1, 1, 1]
     assert mask[1].tolist() == [1, 1, 1, 1, 1, 1, 0, 0] and ids[1, 6:].tolist() == [0, 0]
+
+
+def test_rerank_pairs_keep_the_closing_token_when_cut(tmp_path):
+    """A tokenizer with no truncation configured: pairs longer than max_length are cut here and still end in [SEP]."""
+    from rag_amd.embeddings import _load_tokenizer
+    from rag_amd.retrievers import rerank_pairs_csr
+    _write_model_dir(str(tmp_path / "m"))
+    tok = _load_tokenizer(str(tmp_path / "m"), max_len=32)
+    tok.no_truncation()
+    long_doc = Document(page_content=" ".join(["cat", "sat", "mat", "dogs"] * 10))
+    ids, types, mask = rerank_pairs("red mat", [long_doc, Document(page_content="dogs")], tok, max_length=12)
+    assert ids.shape == (2, 12) and ids[0, -1] == 3 and types[0, -1] == 1 and mask[0].all()      # [SEP] of segment 1
+    assert ids[0, :4].tolist() == [2, 13, 9, 3]
+    f_ids, f_types, off = rerank_pairs_csr([("red mat", long_doc.page_content), ("red mat", "dogs")], tok, max_length=12)
+    assert off.tolist() == [0, 12, 18] and f_ids[11] == 3 and f_types[11] == 1 and f_ids[17] == 3
+
+
+def test_rank_with_a_multi_label_head_needs_a_column():
+    from rag_amd.retrievers import CrossEncoderReranker
+
+    class _Enc:                                            # a test double: logits from the passage length
+        def classify(self, ids, types, mask):
+            n = mask.sum(axis=1).astype(np.float32)
+            return np.stack([n, -n], axis=1)
+
+    class _Tok:
+        def encode(self, q, p):
+            class E:
+                pass
+            e = E()
+            e.ids = [2] + [5] * len(q.split()) + [3] + [6] * len(p.split()) + [3]
+            e.type_ids = [0] * (len(q.split()) + 2) + [1] * (len(p.split()) + 1)
+            return e
+
+    docs = [Document(page_content="a b c"), Document(page_content="a"), Document(page_content="a b c d e")]
+    rr = CrossEncoderReranker(encoder=_Enc(), tokenizer=_Tok(), max_length=64)
+    assert rr.predict([("q", d.page_content) for d in docs]).shape == (3, 2)
+    with pytest.raises(ValueError):
+        rr.rank("q", docs)
+    by0 = CrossEncoderReranker(encoder=_Enc(), tokenizer=_Tok(), max_length=64, score_label=0).rank("q", docs)
+    by1 = CrossEncoderReranker(encoder=_Enc(), tokenizer=_Tok(), max_length=64, score_label=1).rank("q", docs, top_n=2)
+    assert [d.page_content for d in by0] == ["a b c d e", "a b c", "a"]
+    assert [d.page_content for d in by1] == ["a", "a b c"]
