@@ -61,7 +61,10 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 #define MF_SORT_MAX 1024                           // survivors re-scored and sorted per (query, group)
 #define MF_MIN_ROWS 32768
 
-__host__ __device__ constexpr int mf_cap(int kp) { return 2 * kp + 32; }
+#ifndef MF_CAP_EXTRA
+#define MF_CAP_EXTRA 32
+#endif
+__host__ __device__ constexpr int mf_cap(int kp) { return 2 * kp + MF_CAP_EXTRA; }
 // Waves per workgroup and 16-query blocks per wave.  d <= 384: 8 waves x 32 queries (96 VGPRs of query fragments).
 // d = 768: the 32x32x16 (HBM-bound) variant keeps 4 waves x 32 queries, one per SIMD with the 512-register budget;
 // the 16x16x32 (MFMA-bound) variant runs 8 waves x 16 queries, two per SIMD: a wave alone on its SIMD has nothing
@@ -1105,7 +1108,9 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
     // at least ~32 tiles per slice so the running thresholds have time to tighten; with one or two
     // query tiles the scan is a latency problem instead (200,000 rows x 1 query: 48 slices took
     // 293 us on 48 CUs), so there 8 tiles per slice are enough - the lists are rescored exactly anyway
-    const int min_tiles = (nqt <= 2) ? 8 : 32;
+    // (1M x 384 x 1,000 queries, slices of 32 / 65 / 122 tiles: wall 1.64 / 1.36 / 1.42 ms -- below ~64 tiles a slice spends
+    // its life warming its thresholds up, and every slice adds a list per query to the finish: tools/config2_sweep.py)
+    const int min_tiles = (nqt <= 2) ? 8 : 64;
     while (ns > 8 && n / ns < (int64_t)min_tiles * MF_TILE_R) ns -= 8;
     if (ns < 8) ns = 8;
     if (const char* e = getenv("MI_MFMA_NS")) {

@@ -7,6 +7,7 @@ python -m rag_amd._build > /dev/null
 mkdir -p tools/_ab
 FILE=${FILE:-search_mfma}
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function -Wno-inline-asm"
+if [ "$FILE" == "encoder_ffn3" ]; then F="$F -mllvm -amdgpu-spill-vgpr-to-agpr=0"; fi   # as rag_amd/_build.py FILE_FLAGS
 /opt/rocm/bin/hipcc $F $2 -c rag_amd/csrc/$FILE.hip -o tools/_ab/$1_$FILE.o
 OBJS=""
 for o in capi multi ingest search_exact search_mfma encoder encoder_ffn3; do
