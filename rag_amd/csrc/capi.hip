@@ -600,9 +600,9 @@ static int search_dev_locked(mi_index* x, int64_t nq64, const float* q_dev, int 
     MI_TRY(x->cnts.ensure(plan.cnt_bytes));
     MI_TRY(x->thrs.ensure(plan.thr_bytes));
     // shared thresholds [nq_pad], then the scan's per-slice progress words [nslices][64]
-    const size_t gthr_bytes = ((size_t)plan.nq_pad + (size_t)plan.nslices * 64) * sizeof(uint32_t);
-    MI_TRY(x->gthr.ensure(gthr_bytes));
-    MI_HIP(hipMemsetAsync(x->gthr.p, 0, gthr_bytes, st));
+    // (and the seed pass's own block behind them: kernels.h)
+    MI_TRY(x->gthr.ensure(plan.gthr_bytes));
+    MI_HIP(hipMemsetAsync(x->gthr.p, 0, plan.gthr_bytes, st));
     // fail: [0] = count, [64 ..) = list of failed queries, then the per-query overflow flags
     MI_TRY(x->fail.ensure((size_t)(2 * (size_t)nq + 64) * sizeof(int32_t)));
     int32_t* fail_count = x->fail.as<int32_t>();
@@ -611,6 +611,7 @@ static int search_dev_locked(mi_index* x, int64_t nq64, const float* q_dev, int 
     MI_HIP(hipMemsetAsync(fail_count, 0, 256, st));
     MI_HIP(hipMemsetAsync(over_flags, 0, (size_t)nq * sizeof(int32_t), st));
     MI_TRY(ev_begin(x, st));
+    MI_TRY(mi_launch_mfma_seed(st, &plan, x->metric, scan_rows, x->xx, x->d_pad_scan, qb, nq, x->gthr.as<uint32_t>()));
     MI_TRY(mi_launch_mfma_scan(st, &plan, x->metric, scan_rows, x->xx, n, x->d_pad_scan, qb, nq,
                                x->lists.as<uint64_t>(), x->cnts.as<int32_t>(), x->thrs.as<float>(), x->gthr.as<uint32_t>()));
     MI_TRY(ev_end(x, st));

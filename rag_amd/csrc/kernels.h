@@ -69,6 +69,10 @@ struct mi_mfma_plan {
     int64_t slice_rows;// rows per slice (multiple of the tile height)
     int nq_pad;        // queries padded to the query tile
     size_t list_bytes, cnt_bytes, thr_bytes;
+    // threshold seed pass (0 rows: none): the scan kernel in SEED mode over the first seed_rows rows, seed_slices slices
+    int64_t seed_rows;
+    int seed_slices;
+    size_t gthr_bytes; // the shared-threshold block: [nq_pad + 64 nslices] of the scan, then [nq_pad + 64 seed_slices] + [nq_pad][64] of the seed pass
 };
 bool mi_mfma_supported(int d_pad, int k);
 // Row pitch (elements) the scan streams for dimension d: 128 / 384 / 768, or 0 (unsupported).
@@ -80,7 +84,13 @@ void mi_mfma_eps(int d_pad_scan, bool rounded_shadow, float* eps_acc, float* eps
 // rows: bf16 [n][d_pad]; xx: canonical squared norms (L2 only).
 int  mi_launch_mfma_scan(hipStream_t st, const mi_mfma_plan* p, int metric, const uint16_t* rows,
                          const float* xx, int64_t n, int d_pad, const uint16_t* q_bf16, int64_t nq,
-                         uint64_t* lists, int32_t* cnts, float* thrs, uint32_t* gthr /* [nq_pad + 64 nslices], zeroed */);
+                         uint64_t* lists, int32_t* cnts, float* thrs, uint32_t* gthr /* plan->gthr_bytes, zeroed */);
+// Threshold seed (plan->seed_rows > 0; enqueue BEFORE mi_launch_mfma_scan on the same stream): scores the first seed_rows
+// rows against every query with the scan kernel's own arithmetic, keeps the maximum of each of 64 disjoint row classes per
+// query, and writes the 16th largest of the 64 (less one ulp) into gthr[q]: sixteen different rows score above it, so it is
+// a lower bound of the query's 16th best score and every workgroup of the scan starts with it instead of -inf.
+int  mi_launch_mfma_seed(hipStream_t st, const mi_mfma_plan* p, int metric, const uint16_t* rows, const float* xx,
+                         int d_pad, const uint16_t* q_bf16, int64_t nq, uint32_t* gthr);
 // Phase 2: per (query, slice group): prefilter by MFMA score, canonical re-score from the
 // canonical rows (canon_dtype, pitch d_pad), exact top-k at out[q * out_stride + g * k + j].
 // over_flags[q] = 1 where a group had more near-ties than it can sort.

@@ -60,6 +60,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 #define MF_PH2_MAX 8192                            // candidate entries per (query, group) in LDS
 #define MF_SORT_MAX 1024                           // survivors re-scored and sorted per (query, group)
 #define MF_MIN_ROWS 32768
+#define MF_SEED_CLASSES 64                         // disjoint row classes per query in the threshold seed pass
 
 #ifndef MF_CAP_EXTRA
 #define MF_CAP_EXTRA 32
@@ -158,12 +159,17 @@ __device__ __forceinline__ int mf_trace_slot(int b) { return b == 3 ? 0 : b == 3
 #define MF_TRACE_LDS 0
 #endif
 
-template <int NKB, int KP, bool L2, int PD, bool M16>
+// SEED (16x16x32 variant only): no lists, no thresholds -- the kernel keeps, per query, the maximum score of each of 64
+// disjoint row classes (slice mod 4 x lane group g4 x row block mod 4) over the slice and folds them into
+// gmax[q][MF_SEED_CLASSES] with atomic max (mi_launch_mfma_seed).
+template <int NKB, int KP, bool L2, int PD, bool M16, bool SEED = false>
 __global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
     const uint16_t* __restrict__ rows, const float* __restrict__ xx, int64_t n, int pitch_bytes,
     const uint16_t* __restrict__ q_bf16, int nq, int nq_pad, int nqt, int64_t slice_rows,
-    uint64_t* __restrict__ lists, int32_t* __restrict__ cnts, float* __restrict__ thrs, uint32_t* __restrict__ gthr)
+    uint64_t* __restrict__ lists, int32_t* __restrict__ cnts, float* __restrict__ thrs, uint32_t* __restrict__ gthr,
+    uint32_t* __restrict__ gmax)
 {
+    static_assert(!SEED || M16, "the seed pass runs the 16x16x32 variant");
     constexpr int WAVES = mf_waves(NKB, M16);
     constexpr int QB = mf_qb(NKB, M16);               // 16-query blocks per wave
     constexpr int QW = 16 * QB;                       // queries per wave
@@ -666,6 +672,29 @@ __global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
         }
     };
 
+    // ---- SEED: running maxima of the lane's scores in 4 classes (row block mod 4); with the lane group g4 and the slice
+    // number mod 4 that makes MF_SEED_CLASSES = 64 disjoint row classes per query.  (More classes per lane spill in the
+    // d = 384 instance, and a scratch reload drains the LDS-DMA queue: 8 per lane 109 us, 16 per lane 245 us for the pass
+    // against 52.)
+    float gm[SEED ? QB : 1][4];
+    if constexpr (SEED) {
+#pragma unroll
+        for (int cb = 0; cb < QB; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gm[cb][j] = -__builtin_inff();
+    }
+    auto seed_tile = [&]() __attribute__((always_inline)) {
+        if constexpr (M16 && SEED) {
+#pragma unroll
+            for (int cb = 0; cb < QB; ++cb)
+#pragma unroll
+                for (int rb = 0; rb < 8; ++rb) {                                        // (fmax drops a NaN score)
+                    const float m01 = __builtin_fmaxf(acc16[rb][cb][0], acc16[rb][cb][1]), m23 = __builtin_fmaxf(acc16[rb][cb][2], acc16[rb][cb][3]);
+                    gm[cb][rb & 3] = __builtin_fmaxf(gm[cb][rb & 3], __builtin_fmaxf(m01, m23));
+                }
+        }
+    };
+
     // my LDS reads are retired; my pieces of unit u + 1 have landed; everyone meets
     auto end_of_unit = [&](int u) __attribute__((always_inline)) {
         const int rem = nunits - 2 - u;               // units younger than u + 1 that exist
@@ -719,7 +748,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
                         }
                     }
                 }
-                if constexpr (kb == NKB - 1) { if (active) refresh_thr(tile); }
+                if constexpr (kb == NKB - 1 && !SEED) { if (active) refresh_thr(tile); }
                 auto mid = [&]() __attribute__((always_inline)) {
                     stamp(1);
                     if constexpr (MF_LEAD == 10 && MF_ASYM) {
@@ -763,7 +792,7 @@ __global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
                 stamp(6);
                 if constexpr (kb == NKB - 1) {
                     if (active) {
-                        filter_tile(tile);
+                        if constexpr (SEED) seed_tile(); else filter_tile(tile);
                         if constexpr (L2) { if (tile + 1 < ntiles) init_acc(tile + 1); }
                     }
                 }
@@ -815,7 +844,16 @@ __global__ __launch_bounds__(64 * mf_waves(NKB, M16)) void mfma_scan_kernel(
     }
 #endif
 
-    if constexpr (M16) {
+    if constexpr (SEED) {
+        if (threadIdx.x == 0 && nqt <= 64) __hip_atomic_store(prog + qt, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (active && ntiles > 0) {
+#pragma unroll
+            for (int cb = 0; cb < QB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    __hip_atomic_fetch_max(gmax + (qbase + 16 * cb + l15) * MF_SEED_CLASSES + 16 * (slice & 3) + 4 * g4 + j, mi_ord_f32(gm[cb][j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if constexpr (M16) {
         if (threadIdx.x == 0 && nqt <= 64) __hip_atomic_store(prog + qt, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (g4 == 0) {
 #pragma unroll
@@ -915,13 +953,17 @@ __global__ __launch_bounds__(256) void mfma_finish_kernel(
     const int s1 = (s0 + spg < ns) ? s0 + spg : ns;
     const int nsl = s1 - s0;
 
+    // list lengths of the group's slices: loaded by as many threads (one strided word each -- read one after the other by
+    // a single thread they were half of this kernel's time at 120 slices), then summed from LDS
+    for (int s = t; s < nsl; s += 256) offs[s + 1] = cnts[(int64_t)(s0 + s) * nq_pad + q];
+    for (int c = t; c < d_pad; c += 256) qrow[c] = q_canon[q * d_pad + c];
+    __syncthreads();
     if (t == 0) {
         int o = 0;
-        for (int s = 0; s < nsl; ++s) { offs[s] = o; o += cnts[(int64_t)(s0 + s) * nq_pad + q]; }
-        offs[nsl] = o;
+        offs[0] = 0;
+        for (int s = 1; s <= nsl; ++s) { o += offs[s]; offs[s] = o; }
         s_nsurv = 0;
     }
-    for (int c = t; c < d_pad; c += 256) qrow[c] = q_canon[q * d_pad + c];
     __syncthreads();
     const int total = offs[nsl];                       // <= spg * cap <= MF_PH2_MAX
     const float qqv = qq[q];
@@ -1108,9 +1150,10 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
     // at least ~32 tiles per slice so the running thresholds have time to tighten; with one or two
     // query tiles the scan is a latency problem instead (200,000 rows x 1 query: 48 slices took
     // 293 us on 48 CUs), so there 8 tiles per slice are enough - the lists are rescored exactly anyway
-    // (1M x 384 x 1,000 queries, slices of 32 / 65 / 122 tiles: wall 1.64 / 1.36 / 1.42 ms -- below ~64 tiles a slice spends
-    // its life warming its thresholds up, and every slice adds a list per query to the finish: tools/config2_sweep.py)
-    const int min_tiles = (nqt <= 2) ? 8 : 64;
+    // (1M x 384 x 1,000 queries with the threshold seed below, 120 / 192 / 256 slices: scan 0.82 / 0.72 / 0.69 ms, wall
+    // 0.95 / 0.91 / 0.89 -- a workgroup's start-up is paid once per round of 256 workgroups either way, shorter slices
+    // balance the last round better: tools/config2_sweep.py)
+    const int min_tiles = (nqt <= 2) ? 8 : 32;
     while (ns > 8 && n / ns < (int64_t)min_tiles * MF_TILE_R) ns -= 8;
     if (ns < 8) ns = 8;
     if (const char* e = getenv("MI_MFMA_NS")) {
@@ -1125,6 +1168,23 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
     plan->spg = (ns + ngroups - 1) / ngroups;
     plan->slice_rows = mi_round_up((n + ns - 1) / ns, MF_TILE_R);
     plan->nq_pad = (int)(nqt * qtile);
+    // Threshold seed: K' = 16 lists (k <= 15: the seed guarantees 16 rows above it, no more) scored by the 16x16x32
+    // variant.  A sixteenth of the corpus up to 65,536 rows, in slices of whole tiles on >= ~256 workgroups; below
+    // 8,192 rows it would not tighten anything.  What it buys: a slice no longer spends its first tiles with thresholds
+    // that pass every row (1M x 384 x 1,000 queries: scan 1.23 -> see DESIGN.md 4.1), and costs seed_rows / n of the scan.
+    plan->seed_rows = 0;
+    plan->seed_slices = 0;
+    if (kp == 16 && plan->m16 && !(getenv("MI_MFMA_SEED") && atoi(getenv("MI_MFMA_SEED")) == 0)) {
+        int ss = (int)mi_round_up((256 + nqt - 1) / nqt, 8);
+        if (ss > 64) ss = 64;
+        int64_t want = n / 16;
+        if (want > 65536) want = 65536;
+        if (const char* e = getenv("MI_MFMA_SEED_ROWS")) { const int64_t v = atoll(e); if (v > 0 && v <= n) want = v; }
+        while (ss > 8 && want / ss < 2 * MF_TILE_R) ss -= 8;
+        const int64_t per = want / ss / MF_TILE_R * MF_TILE_R;         // whole tiles per slice: no row past the sample
+        if (per * ss >= 8192) { plan->seed_rows = per * ss; plan->seed_slices = ss; }
+    }
+    plan->gthr_bytes = ((size_t)plan->nq_pad + (size_t)ns * 64 + (size_t)plan->nq_pad + (size_t)plan->seed_slices * 64 + (size_t)plan->nq_pad * MF_SEED_CLASSES) * sizeof(uint32_t);
     plan->list_bytes = (size_t)ns * plan->nq_pad * cap * sizeof(uint64_t);
     plan->cnt_bytes = (size_t)ns * plan->nq_pad * sizeof(int32_t);
     plan->thr_bytes = (size_t)ns * plan->nq_pad * sizeof(float);
@@ -1139,7 +1199,52 @@ static void launch_scan(hipStream_t st, const mi_mfma_plan* p, const uint16_t* r
     const int nqt = p->nq_pad / qtile;
     const unsigned grid = (unsigned)(nqt * p->nslices);
     mfma_scan_kernel<NKB, KP, L2, PD, M16><<<grid, 64 * mf_waves(NKB, M16), 0, st>>>(rows, xx, n, d_pad * 2, q_bf16, nq, p->nq_pad, nqt,
-                                                                       p->slice_rows, lists, cnts, thrs, gthr);
+                                                                       p->slice_rows, lists, cnts, thrs, gthr, nullptr);
+}
+
+// One wave per query: gthr[q] = (the 16th largest of the query's MF_SEED_CLASSES class maxima) - 1 ulp.  Sixteen classes -- sixteen
+// different rows -- score at or above that word, so it is a lower bound of the query's 16th best score.
+__global__ __launch_bounds__(256) void mfma_seed_min_kernel(const uint32_t* __restrict__ gmax, int nq, uint32_t* __restrict__ gthr)
+{
+    static_assert(MF_SEED_CLASSES <= 64, "one class per lane");
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const uint32_t w = lane < MF_SEED_CLASSES ? gmax[(size_t)q * MF_SEED_CLASSES + lane] : 0u;
+    uint32_t T = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = T | (1u << bit);
+        if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(w >= cand)) >= 16) T = cand;
+    }
+    // (at or below ord(-inf) = 0x007FFFFF: fewer than 16 classes saw a finite score; leave the query unseeded)
+    if (lane == 0 && T > 0x00800000u) atomicMax(gthr + q, T - 1u);
+}
+
+template <int NKB, bool L2>
+static void launch_seed(hipStream_t st, const mi_mfma_plan* p, const uint16_t* rows, const float* xx, int d_pad,
+                        const uint16_t* q_bf16, int nq, uint32_t* gthr)
+{
+    static_assert(mf_qtile(NKB, true) > 0, "");
+    const int nqt = p->nq_pad / mf_qtile(NKB, true);
+    uint32_t* const seed_gthr = gthr + p->nq_pad + (size_t)p->nslices * 64;      // zero thresholds + the seed launch's progress words
+    uint32_t* const gmax = seed_gthr + p->nq_pad + (size_t)p->seed_slices * 64;
+    mfma_scan_kernel<NKB, 16, L2, 2, true, true><<<(unsigned)(nqt * p->seed_slices), 64 * mf_waves(NKB, true), 0, st>>>(
+        rows, xx, p->seed_rows, d_pad * 2, q_bf16, nq, p->nq_pad, nqt, p->seed_rows / p->seed_slices, nullptr, nullptr, nullptr, seed_gthr, gmax);
+    mfma_seed_min_kernel<<<(unsigned)((nq + 3) / 4), 256, 0, st>>>(gmax, nq, gthr);
+}
+
+int mi_launch_mfma_seed(hipStream_t st, const mi_mfma_plan* p, int metric, const uint16_t* rows, const float* xx,
+                        int d_pad, const uint16_t* q_bf16, int64_t nq, uint32_t* gthr)
+{
+    if (p->seed_rows <= 0) return MI_OK;
+    const int nkb = pick_nkb(d_pad);
+    const bool l2 = metric == MI_METRIC_L2;
+    if (nkb == 1) { if (l2) launch_seed<1, true>(st, p, rows, xx, d_pad, q_bf16, (int)nq, gthr); else launch_seed<1, false>(st, p, rows, xx, d_pad, q_bf16, (int)nq, gthr); }
+    else if (nkb == 3) { if (l2) launch_seed<3, true>(st, p, rows, xx, d_pad, q_bf16, (int)nq, gthr); else launch_seed<3, false>(st, p, rows, xx, d_pad, q_bf16, (int)nq, gthr); }
+    else if (nkb == 6) { if (l2) launch_seed<6, true>(st, p, rows, xx, d_pad, q_bf16, (int)nq, gthr); else launch_seed<6, false>(st, p, rows, xx, d_pad, q_bf16, (int)nq, gthr); }
+    else { mi_set_error("mfma seed: no kernel for d_pad=%d", d_pad); return MI_ERR_UNSUPPORTED; }
+    MI_HIP(hipGetLastError());
+    return MI_OK;
 }
 
 int mi_launch_mfma_scan(hipStream_t st, const mi_mfma_plan* p, int metric, const uint16_t* rows,
