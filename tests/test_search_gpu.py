@@ -478,3 +478,39 @@ def test_bench_size_properties(oracle_mod):
     assert np.array_equal(I7, I[sub]) and np.array_equal(D7.view(np.uint32), D[sub].view(np.uint32))
     ne = _exact_cross_check(idx, Q, D, I, k, len(planted))
     print(f"config 4: {ne} queries bit-equal on the exact path")
+
+
+@pytest.mark.parametrize("metric,dtype", [("ip", "bf16"), ("l2", "bf16"), ("ip", "f32"), ("l2", "f32")])
+def test_threshold_seed_keeps_the_answer(oracle_mod, metric, dtype, monkeypatch):
+    """The seed pass (more than 128 queries, k <= 15) starts every slice at the 16th largest of 64 class maxima of a row
+    sample.  Adversarial for it: the sample (the index's first rows) holds near-copies of some queries -- so their seed
+    is as tight as it can get -- a NaN row, zero rows and a block of identical rows; the true neighbours of other queries
+    lie only behind the sample.  Seeded and unseeded (MI_MFMA_SEED=0, read per call) answers equal the oracle's bits."""
+    from rag_amd.index import FlatIndex, MODE_FAST
+    n, d, nq, k = 300_000, 384, 300, 10
+    rng = np.random.default_rng(77)
+    X = _unit(rng, n, d)
+    Q = _unit(rng, nq, d)
+    for j in range(20):                                   # twenty near-copies of query 0 inside the sample, six of query 1
+        X[50 + 37 * j] = Q[0] + 0.01 * (j + 1) * X[50 + 37 * j]
+    for j in range(6):
+        X[900 + 11 * j] = Q[1] * (1.0 - 0.001 * j)
+    for j in range(12):                                   # query 2's neighbours lie far behind the sample
+        X[200_000 + 1000 * j] = Q[2] * (1.0 - 0.002 * j)
+    X[123] = np.nan
+    X[300:310] = 0.0
+    X[5000:5040] = X[5000]                                # identical rows: ties across the class maxima
+    m = {"ip": oracle_mod.METRIC_IP, "l2": oracle_mod.METRIC_L2}[metric]
+    t = {"f32": oracle_mod.DTYPE_F32, "bf16": oracle_mod.DTYPE_BF16}[dtype]
+    Do, Io = oracle_mod.search(X, Q, k, metric=m, dtype=t)
+    idx = FlatIndex(d, metric=metric, dtype=dtype)
+    idx.set_mode(MODE_FAST)
+    idx.add(X)
+    for seed in ("1", "0"):
+        monkeypatch.setenv("MI_MFMA_SEED", seed)
+        before = idx.stats()
+        D, I = idx.search(Q, k)
+        after = idx.stats()
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+        assert after["fast"] - before["fast"] >= 0.9 * nq, (seed, before, after)
