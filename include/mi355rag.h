@@ -299,6 +299,20 @@ int  mi_encoder_encode_dev_noalloc(mi_encoder* enc, int64_t B, int L, const int3
 /* Timing of the last encode pass (all kernels), HIP events on its stream. */
 int  mi_encoder_last_time(const mi_encoder* enc, float* out_ms);
 
+/* ---- host text path: WordPiece tokenizer (pure host code, no GPU call)
+ * Replaces, for ASCII input, the tokenizer advanced_rag.py:104-107 reaches through HuggingFaceEmbeddings ->
+ * sentence-transformers -> `tokenizers` (BertNormalizer, BertPreTokenizer, WordPiece, [CLS] .. [SEP], truncation):
+ * embed_documents (advanced_rag.py:295) from List[str] was bound by it.  vocab: the bytes of vocab.txt (one entry per
+ * line, line number = id).  encode_batch: text i = text[text_offsets[i] .. text_offsets[i + 1]); out_ids holds n rows of
+ * max_len ids, row i filled with out_lens[i] of them ([CLS] pieces [SEP], cut to max_len); out_lens[i] = -1 marks a text
+ * with a byte >= 0x80 or a spelled-out special token ("[" A-Z+ "]"), which is left to the reference tokenizer.  n_threads <= 0:
+ * OMP_NUM_THREADS, else min(16, cores). */
+typedef struct mi_wordpiece mi_wordpiece;
+int  mi_wordpiece_create(const char* vocab, int64_t vocab_bytes, int lowercase, mi_wordpiece** out);
+void mi_wordpiece_destroy(mi_wordpiece* wp);
+int  mi_wordpiece_encode_batch(const mi_wordpiece* wp, const char* text, const int64_t* text_offsets, int64_t n,
+                               int max_len, int n_threads, int32_t* out_ids, int64_t* out_lens);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "..", "build", "obj")
 LIB = os.path.join(LIBDIR, "libmi355rag.so")
 
-SOURCES = ["capi.hip", "multi.hip", "ingest.hip", "search_exact.hip", "search_mfma.hip", "encoder.hip", "encoder_ffn3.hip"]
+SOURCES = ["capi.hip", "multi.hip", "ingest.hip", "search_exact.hip", "search_mfma.hip", "encoder.hip", "encoder_ffn3.hip", "wordpiece.hip"]
 HEADERS = ["common.h", "kernels.h", "encoder_ffn3.h", os.path.join("..", "..", "include", "mi355rag.h")]
 
 # -ffp-contract=off: the canonical score is an explicit fmaf chain; nothing else may be fused.

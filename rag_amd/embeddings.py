@@ -175,6 +175,117 @@ def _load_tokenizer(path: str, max_len: int):
     return tok
 
 
+def _is_standard_bert_pipeline(tok) -> Optional[bool]:
+    """None unless the tokenizer is the stock BERT pipeline the native WordPiece restates (BertNormalizer with clean_text,
+    BertPreTokenizer, WordPiece with [UNK] / ## / 100 characters, [CLS] $A [SEP]); else its `lowercase` flag."""
+    import json
+    try:
+        cfg = json.loads(tok.to_str())
+        nz, pt, md, pp = cfg.get("normalizer") or {}, cfg.get("pre_tokenizer") or {}, cfg.get("model") or {}, cfg.get("post_processor") or {}
+        if nz.get("type") != "BertNormalizer" or not nz.get("clean_text", False) or pt.get("type") != "BertPreTokenizer":
+            return None
+        if md.get("type") != "WordPiece" or md.get("unk_token") != "[UNK]" or md.get("continuing_subword_prefix") != "##":
+            return None
+        if int(md.get("max_input_chars_per_word", 100)) != 100:
+            return None
+        if pp.get("type") == "BertProcessing":
+            if pp.get("cls", [None])[0] != "[CLS]" or pp.get("sep", [None])[0] != "[SEP]":
+                return None
+        elif pp.get("type") == "TemplateProcessing":
+            single = [(list(x.keys())[0], list(x.values())[0].get("id")) for x in pp.get("single", [])]
+            if single != [("SpecialToken", "[CLS]"), ("Sequence", "A"), ("SpecialToken", "[SEP]")]:
+                return None
+        else:
+            return None
+        import re
+        if any(not a.get("special", False) or not re.fullmatch(r"\[[A-Z]+\]", a.get("content", "")) for a in cfg.get("added_tokens") or []):
+            return None                                   # added words bypass WordPiece; the native path steps aside only for "[" A-Z+ "]"
+        return bool(nz.get("lowercase", True))
+    except Exception:
+        return None
+
+
+class NativeWordPiece:
+    """mi_wordpiece_* (rag_amd/csrc/wordpiece.hip): the stock BERT tokenizer pipeline for ASCII texts in C++ on all host
+    cores, straight into the CSR arrays mi_encoder_encode_ragged takes.  Texts with non-ASCII characters keep going
+    through `tokenizers` (accents, CJK, Unicode categories are not restated), so the result is the reference tokenizer's
+    for every input: tests/test_wordpiece.py.  Built only for the stock pipeline, and only if a probe of the vocabulary
+    reproduces `tokenizers` token for token."""
+
+    def __init__(self, tok, max_len: int, n_threads: int = 0):
+        lower = _is_standard_bert_pipeline(tok)
+        if lower is None:
+            raise ValueError("not the stock BERT WordPiece pipeline")
+        vocab = tok.get_vocab()
+        size = max(vocab.values()) + 1
+        entries = [""] * size
+        for t, i in vocab.items():
+            if "\n" in t or "\r" in t:
+                raise ValueError("vocabulary entry with a line break")
+            entries[i] = t
+        blob = "\n".join(entries).encode("utf-8")
+        self._lib = _capi.load()
+        h = ctypes.c_void_p()
+        _capi.check(self._lib.mi_wordpiece_create(blob, len(blob), 1 if lower else 0, ctypes.byref(h)))
+        self._h, self.tok, self.max_len, self.n_threads = h, tok, int(max_len), int(n_threads)
+        probe = ["", "Hello, World!  a-b_c", "x" * 101 + " " + "y" * 100, "The quick\tbrown\nfox's 12345.678 #tag ##ing [SEP] [MASK]",
+                 "tab\x0bsep\x00nul\x7fdel", " ".join(list(vocab)[:: max(1, len(vocab) // 200)][:300])]
+        probe = [p for p in probe if p.isascii()]
+        flat, off = self.encode_csr(probe, _self_check=True)
+        ref = [e.ids for e in tok.encode_batch(probe)]
+        for i, r in enumerate(ref):
+            if flat[off[i]:off[i + 1]].tolist() != r:
+                self.close()
+                raise ValueError(f"native WordPiece disagrees with tokenizers on probe {i}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi_wordpiece_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode_csr(self, texts: List[str], _self_check: bool = False):
+        """texts -> (flat int32 ids, int64 offsets [n + 1]), each text as [CLS] pieces [SEP] cut to max_len."""
+        n = len(texts)
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        if n == 0:
+            return np.zeros(0, dtype=np.int32), offsets
+        ascii_mask = np.fromiter((t.isascii() for t in texts), dtype=bool, count=n)
+        nat = np.flatnonzero(ascii_mask)
+        rows = np.empty((n, self.max_len), dtype=np.int32)
+        lens = np.zeros(n, dtype=np.int64)
+        if nat.size:
+            sub = texts if nat.size == n else [texts[i] for i in nat]
+            blob = "".join(sub).encode("ascii")
+            toff = np.zeros(nat.size + 1, dtype=np.int64)
+            np.cumsum(np.fromiter((len(t) for t in sub), dtype=np.int64, count=nat.size), out=toff[1:])
+            sub_rows = rows if nat.size == n else np.empty((nat.size, self.max_len), dtype=np.int32)
+            sub_lens = lens if nat.size == n else np.zeros(nat.size, dtype=np.int64)
+            _capi.check(self._lib.mi_wordpiece_encode_batch(self._h, blob, toff.ctypes.data_as(ctypes.c_void_p), nat.size, self.max_len,
+                                                            self.n_threads, sub_rows.ctypes.data_as(ctypes.c_void_p),
+                                                            sub_lens.ctypes.data_as(ctypes.c_void_p)))
+            if nat.size != n:
+                rows[nat] = sub_rows
+                lens[nat] = sub_lens
+            ascii_mask = ascii_mask & (lens >= 0)                                # (-1: a spelled-out special token)
+        rest = np.flatnonzero(~ascii_mask)
+        self.last_native_texts = int(n - rest.size)                             # (the others went through `tokenizers`)
+        if rest.size:
+            fn = getattr(self.tok, "encode_batch_fast", None) or self.tok.encode_batch
+            for i, e in zip(rest, fn([texts[i].replace("\n", " ") for i in rest])):
+                ids = e.ids
+                rows[i, :len(ids)] = ids
+                lens[i] = len(ids)
+        np.cumsum(lens, out=offsets[1:])
+        flat = rows[np.arange(self.max_len)[None, :] < lens[:, None]]          # row-major: every text's ids in order
+        return np.ascontiguousarray(flat, dtype=np.int32), offsets
+
+
 class MI355Embeddings:
     """HuggingFaceEmbeddings-compatible: model_name (local dir), model_kwargs, encode_kwargs.
 
@@ -203,6 +314,13 @@ class MI355Embeddings:
         cfg, blob = load_local_dir(model_name, normalize=normalize)
         self.max_seq_length = min(int(max_seq_length), int(cfg.max_position_embeddings))
         self.tokenizer = _load_tokenizer(model_name, self.max_seq_length)
+        # the stock BERT pipeline on ASCII text runs natively (mi_wordpiece_*); anything else stays with `tokenizers`
+        self.native_tokenizer = None
+        if os.environ.get("MI_NATIVE_TOKENIZER", "1") != "0":
+            try:
+                self.native_tokenizer = NativeWordPiece(self.tokenizer, self.max_seq_length)
+            except (ValueError, _capi.MI355Error):
+                self.native_tokenizer = None
         self.encoders = [Encoder(cfg, blob, device=d) for d in self.devices]
         self.encoder = self.encoders[0]
         self.slab_texts = max(1, int(slab_texts))
@@ -228,6 +346,8 @@ class MI355Embeddings:
         return flat, offsets
 
     def _tokenize_csr(self, texts: List[str]) -> tuple:
+        if self.native_tokenizer is not None:
+            return self.native_tokenizer.encode_csr(texts)
         return self._to_csr(self._tokenize([t.replace("\n", " ") for t in texts]))
 
     def _encode_csr(self, flat_ids: np.ndarray, offsets: np.ndarray) -> np.ndarray:
