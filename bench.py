@@ -185,12 +185,23 @@ def bench_embed(args, dev, rank, world, barrier):
             t0 = time.perf_counter()
             emb._tokenize_csr(texts[:1024])
             tok_rate = 1024 / (time.perf_counter() - t0)
+            # the reference library on the same texts, and that the native tokenizer returns its tokens
+            t0 = time.perf_counter()
+            ref_ids = [e.ids for e in (getattr(emb.tokenizer, "encode_batch_fast", None) or emb.tokenizer.encode_batch)(texts[:1024])]
+            ref_rate = 1024 / (time.perf_counter() - t0)
+            nat = emb.native_tokenizer is not None
+            tok_equal = None
+            if nat:
+                f_, o_ = emb._tokenize_csr(texts[:1024])
+                tok_equal = all(f_[o_[i]:o_[i + 1]].tolist() == ref_ids[i] for i in range(1024))
             res["from_texts"] = {"value": round(B / el_t, 1), "unit": "chunks/s", "texts": B, "tokens": tm["tokens"],
                                  "frac_of_via_api": round((B / el_t) / (chunks / el_api / world), 4),
                                  "tokenize_s": round(tm["tokenize_s"], 3), "gpu_encode_s": round(tm["encode_s"], 3), "total_s": round(el_t, 3),
                                  "tokenizer_texts_per_s": round(tok_rate, 1), "host_threads": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
                                  "bound": "host tokenizer" if tm["tokenize_s"] > tm["encode_s"] else "gpu",
-                                 "path": "List[str] -> tokenizers WordPiece (encode_batch_fast, all host cores) -> CSR -> mi_encoder_encode_ragged -> "
+                                 "tokenizer": "native mi_wordpiece_* (ASCII texts; others through tokenizers)" if nat else "tokenizers",
+                                 "reference_tokenizer_texts_per_s": round(ref_rate, 1), "tokens_equal_reference_tokenizer": tok_equal,
+                                 "path": "List[str] -> WordPiece on all host cores -> CSR -> mi_encoder_encode_ragged -> "
                                          "fp32 rows; slabs of 1,024 texts, tokenising overlapped with the GPU",
                                  "finite": bool(np.isfinite(Et).all())}
             del emb
