@@ -1153,7 +1153,8 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
     // (1M x 384 x 1,000 queries with the threshold seed below, 120 / 192 / 256 slices: scan 0.82 / 0.72 / 0.69 ms, wall
     // 0.95 / 0.91 / 0.89 -- a workgroup's start-up is paid once per round of 256 workgroups either way, shorter slices
     // balance the last round better: tools/config2_sweep.py)
-    const int min_tiles = (nqt <= 2) ? 8 : 32;
+    // (30, not 32: 1M rows / 256 slices is 30.5 tiles, and 4 query tiles x 256 slices fill whole rounds of 256 workgroups)
+    const int min_tiles = (nqt <= 2) ? 8 : 30;
     while (ns > 8 && n / ns < (int64_t)min_tiles * MF_TILE_R) ns -= 8;
     if (ns < 8) ns = 8;
     if (const char* e = getenv("MI_MFMA_NS")) {
