@@ -11,7 +11,8 @@
 //                     so each lane owns one query's scores, online softmax in registers, the
 //                     P tile re-used as the next MFMA's B operand without leaving registers
 //                                                                          (:111-136)
-//   ffn_ln_kernel     per 128-row tile: [attention output projection + residual + LayerNorm]
+//   ffn3_kernel       (encoder_ffn3.hip; hidden 384 / intermediate 1536, the default layer tail) and
+//   ffn2_kernel       per 128-row tile: [attention output projection + residual + LayerNorm]
 //                     -> FFN1 + erf-GELU -> FFN2 + residual + LayerNorm; neither the
 //                     post-attention hidden state nor the 1536-wide intermediate leaves the CU
 //                                                                          (:289-293, :334-351)
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const uint16_t* __restrict
 }
 
 #ifdef FF_TRACE
-// Debug build only (tools/build_trace.sh): cycle stamps of the phases of eight workgroups of ffn_ln_kernel.
+// Debug build only (tools/build_trace.sh): cycle stamps of the phases of eight workgroups of ffn2_kernel.
 __device__ uint32_t ff_trace_buf[8][8][48];
 #define FF_STAMP(k) do { if (ff_slot >= 0 && lane == 0) ff_trace_buf[ff_slot][wave][k] = (uint32_t)__builtin_amdgcn_s_memtime(); } while (0)
 // stamps INSIDE one stage (FF_TRACE_KT): s_memtime into SGPRs without a wait (a wait would drain the fragment reads in
@@ -731,7 +732,7 @@ __device__ __forceinline__ void ln_rows_epilogue(char* lds, const float* prm, f3
 
 // The main loop of the row-complete GEMM: acc = A[m0 .. m0 + 127][K] * W^T for all 384 columns, the residual rows
 // requested on the way (rres), bias / gamma / beta copied to LDS behind the ring.  Ends with a workgroup
-// barrier: the ring is free.  Shared by gemm_ln_kernel and the front phase of ffn_ln_kernel.
+// barrier: the ring is free.  Shared by gemm_ln_kernel and the front phase of ffn2_kernel.
 __device__ __forceinline__ void rowgemm384_mainloop(char* lds, const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
         const float* __restrict__ bias, const uint16_t* __restrict__ resid, const float* __restrict__ gamma,
         const float* __restrict__ beta, int M, int K, int a_blocked, int m0, int lane, int wave,
@@ -946,261 +947,9 @@ __global__ __launch_bounds__(256) void cvt_pack_w1_kernel(const float* __restric
 }
 
 
-// FRONT: the attention output projection + residual + LayerNorm (what gemm_ln_kernel does for K = 384) runs first, on the
-// same 128 rows: h is then the layer's input (the residual of that LayerNorm), its result never goes to HBM -- it is
-// parked in LDS, becomes the h fragments of step 1 and the residual of the final LayerNorm.
-template <bool FRONT>
-__global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict__ h, const uint16_t* __restrict__ W1p,
-        const float* __restrict__ b1, const uint16_t* __restrict__ W2p, const float* __restrict__ b2,
-        const float* __restrict__ gamma, const float* __restrict__ beta, float eps, uint16_t* __restrict__ out, int M, int I,
-        const uint16_t* __restrict__ ctx, const uint16_t* __restrict__ Wo_p, const float* __restrict__ bo,
-        const float* __restrict__ gamma1, const float* __restrict__ beta1)
-{
-    __shared__ __attribute__((aligned(1024))) char lds[FF_B1_OFF + 1536 * 4];
-    static_assert(FF_B1_OFF + 1536 * 4 <= 160 * 1024, "LDS");
-    static_assert(6 * FF_WS >= 4096 + 128 * LN_TS + 3 * LN_N * 4, "the epilogue's scratch fits in the rings");
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = (int)(gridDim.x - 1 - blockIdx.x) * 128;
-    const int nkt = I / 32;                                        // >= 4
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-#ifdef FF_TRACE
-    const int ff_slot = (blockIdx.x % 64 == 0 && blockIdx.x / 64 < 8) ? (int)(blockIdx.x / 64) : -1;
-    if (ff_slot >= 0 && lane == 0) ff_trace_buf[ff_slot][wave][15] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
-    FF_STAMP(0);
-
-    // b1 -> LDS
-    for (int i = threadIdx.x; i < I / 4; i += 512)
-        *reinterpret_cast<float4*>(lds + FF_B1_OFF + i * 16) = *reinterpret_cast<const float4*>(b1 + 4 * i);
-    f32x4 acc[2][12];
-    // h fragments of the wave's 16 rows (B operand of step 1): lane (l15, g4): row 16 w + l15, k = 32 s + 8 g4 ..
-    bf16x8 hq[12];
-    if constexpr (FRONT) {
-        static_assert(FF_B1_OFF >= 4 * LN_STAGE + 3 * LN_N * 4, "b1 sits behind the front phase's ring and parameters");
-        uint2 rres[2][12];
-        rowgemm384_mainloop(lds, ctx, Wo_p, bo, h, gamma1, beta1, M, LN_N, 1, m0, lane, wave, acc, rres);
-        FF_STAMP(1);
-        ln_rows_epilogue<false>(lds, reinterpret_cast<const float*>(lds + 4 * LN_STAGE), acc, rres, nullptr, m0, M, eps, wm, wn, l15, g4);
-        FF_STAMP(2);
-#pragma unroll
-        for (int sk = 0; sk < 12; ++sk)
-            hq[sk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + 4096 + (16 * wave + l15) * LN_TS + (32 * sk + 8 * g4) * 2));
-#pragma unroll
-        for (int sk = 0; sk < 12; ++sk) asm volatile("" :: "v"(hq[sk]));
-        __syncthreads();                                           // the parked tile gives way to the weight rings
-    } else {
-        int m = m0 + 16 * wave + l15; if (m > M - 1) m = M - 1;
-#pragma unroll
-        for (int sk = 0; sk < 12; ++sk)
-            hq[sk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(h + (int64_t)m * LN_N + 32 * sk + 8 * g4));
-#pragma unroll
-        for (int sk = 0; sk < 12; ++sk) asm volatile("" :: "v"(hq[sk]));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    FF_STAMP(3);
-
-    // ---- LDS-DMA: per block 24 pieces of 1 KB; wave w issues pieces 3w..3w+2 of each
-    const char* w2src[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int r = 16 * (3 * wave + i) + (lane >> 2);                          // W2 row (output column) 0..383
-        const int ch = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
-        w2src[i] = reinterpret_cast<const char*>(W2p) + (int64_t)r * 64 + ch * 16;
-    }
-    const char* w1src = reinterpret_cast<const char*>(W1p) + (3 * wave) * 1024 + lane * 16;
-    auto issue_w2 = [&](int kt) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w2src[i] + (int64_t)kt * FF_WS),
-                (lds_ptr_t)(lds + (kt % 3) * FF_WS + (3 * wave + i) * 1024), 16, 0, 0);
-    };
-    auto issue_w1 = [&](int kt) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w1src + (int64_t)kt * FF_WS + i * 1024),
-                (lds_ptr_t)(lds + FF_W1_OFF + (kt % 3) * FF_WS + (3 * wave + i) * 1024), 16, 0, 0);
-    };
-
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 12; ++nb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[mb][nb][i] = 0.0f;
-
-    const unsigned swz = (unsigned)((0 - (l15 >> 2)) & 3);
-    const unsigned fsw = ((unsigned)g4 ^ swz) << 4;
-    const unsigned a_rd = lds_base + FF_A_OFF + (unsigned)((32 * wm + l15) * 64) + fsw;       // + mb * 1024
-    const unsigned w2_rd = lds_base + (unsigned)((192 * wn + l15) * 64) + fsw;                 // + buf * FF_WS + nb * 1024
-    const unsigned w1_rd = lds_base + FF_W1_OFF + (unsigned)(l15 * 64) + fsw;                  // + buf * FF_WS + s * 2048 + cb * 1024
-    // A write: row 16 w + l15, columns 16 cb + 4 g4 .. + 3 -> chunk 2 cb + (g4 >> 1), half g4 & 1
-    const unsigned a_wr = lds_base + FF_A_OFF + (unsigned)((16 * wave + l15) * 64) + ((((unsigned)g4 >> 1) ^ swz) << 4) + (g4 & 1) * 8;   // cb = 1: ^ 32
-
-    // One fragment group = 4 ds_read_b128 (read one group ahead of its MFMAs, across the step boundary):
-    //   groups 0..2: step 2 of stage kt (W2 fragments of column blocks 4 g .. 4 g + 3, 8 MFMAs each);
-    //   groups 3..8: step 1 of stage kt + 1 (W1 fragments of k-steps 2 sp, 2 sp + 1 x 2 column blocks, 4 MFMAs each).
-    bf16x8 fr[2][4];
-    auto rd_group = [&](bf16x8 (&d)[4], unsigned base) __attribute__((always_inline)) {
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
-                     "ds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
-                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(base));
-    };
-    auto wait4 = [&](bf16x8 (&d)[4]) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
-    };
-    auto wait0 = [&](bf16x8 (&d)[4]) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
-    };
-    // Step 1 runs TWO stages ahead of step 2 and its bias + GELU + store ("finish") one stage later, split in
-    // two halves behind the first two MFMA groups of step 2: 8 values per lane are a long dependent
-    // chain with no parallelism of their own (~500 cycles exposed when they stood at the end of the
-    // stage); behind the MFMAs they cost issue slots only.
-    f32x4 a1n[2], a1p[2];                                          // block being accumulated / block waiting for its finish
-    auto step1_mma = [&](bf16x8 (&d)[4], int sp) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-                a1n[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d[2 * q + cb], hq[2 * sp + q], (sp == 0 && q == 0) ? f32x4{} : a1n[cb], 0, 0, 0);
-    };
-    auto finish_half = [&](int cb, const float4& bb) __attribute__((always_inline)) {
-        float v0 = a1p[cb][0] + bb.x, v1 = a1p[cb][1] + bb.y, v2 = a1p[cb][2] + bb.z, v3 = a1p[cb][3] + bb.w;
-        gelu_erf4(v0, v1, v2, v3);
-        const uint2 o = make_uint2(pack2(v0, v1), pack2(v2, v3));
-        asm volatile("ds_write_b64 %0, %1" :: "v"(a_wr ^ (cb ? 32u : 0u)), "v"(o) : "memory");
-    };
-    auto step1_all = [&](int j) __attribute__((always_inline)) {                // prologue only: no overlap
-        const unsigned wb = w1_rd + (j % 3) * FF_WS;
-        rd_group(fr[0], wb);
-        static_for<6>([&](auto SPc) __attribute__((always_inline)) {
-            constexpr int sp = decltype(SPc)::value;
-            if constexpr (sp < 5) { rd_group(fr[(sp + 1) & 1], wb + (sp + 1) * 4096); wait4(fr[sp & 1]); }
-            else wait0(fr[sp & 1]);
-            step1_mma(fr[sp & 1], sp);
-        });
-    };
-
-    // ---- prologue: A(0) computed, block 1 accumulated, W1(2), W1(3), W2(0), W2(1) landed / in flight
-    issue_w1(0); issue_w1(1); issue_w1(2); issue_w2(0); issue_w2(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    FF_STAMP(4);
-    {
-        float4 bb[2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) bb[cb] = *reinterpret_cast<const float4*>(lds + FF_B1_OFF + (16 * cb + 4 * g4) * 4);
-        step1_all(0);
-        a1p[0] = a1n[0]; a1p[1] = a1n[1];
-        finish_half(0, bb[0]); finish_half(1, bb[1]);
-        step1_all(1);
-        a1p[0] = a1n[0]; a1p[1] = a1n[1];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                  // everyone has left W1(0): its buffer takes W1(3)
-    if (3 < nkt) issue_w1(3);
-    FF_STAMP(5);
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        // behind this barrier: W2(kt) and W1(kt + 2) have landed for everyone (requested two stages ago),
-        // A(kt) is complete, everyone has left stage kt - 1.  In flight: stage kt - 1's requests.
-        FF_TICK(0);
-        {
-            const int young = (kt >= 1) ? ((kt + 1 < nkt ? 3 : 0) + (kt + 3 < nkt ? 3 : 0)) : (3 < nkt ? 3 : 0);
-            if (young == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (young == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        FF_TICKS_OUT(kt - 1);
-        FF_TICK(13);                                               // (13: arrived at the first barrier)
-        __builtin_amdgcn_s_barrier();
-        FF_TICK(1);
-        const bool more1 = kt + 1 < nkt;                           // A(kt + 1) is still to be written (finish of block kt + 1)
-        const bool more2 = kt + 2 < nkt;                           // step 1 of block kt + 2 follows
-        const unsigned w2b = w2_rd + (kt % 3) * FF_WS, w1b = w1_rd + ((kt + 2) % 3) * FF_WS;
-        // (plain loads: hipcc places its own wait before their use)
-        float4 bb[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-        if (more1) {
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) bb[cb] = *reinterpret_cast<const float4*>(lds + FF_B1_OFF + (32 * (kt + 1) + 16 * cb + 4 * g4) * 4);
-        }
-        // the A fragments and the first W2 group, then a second barrier: the A buffer may be overwritten
-        bf16x8 af[2];
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(af[0]), "=&v"(af[1]) : "v"(a_rd));
-        rd_group(fr[0], w2b);
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[0]), "+v"(af[1]));
-        FF_TICK(2);
-        __builtin_amdgcn_s_barrier();
-        FF_TICK(3);
-        static_for<9>([&](auto Gc) __attribute__((always_inline)) {
-            constexpr int g = decltype(Gc)::value;
-            if (g < 3 || more2) {
-                // read the next group, wait for this one
-                if constexpr (g < 2) { rd_group(fr[(g + 1) & 1], w2b + (g + 1) * 4096); wait4(fr[g & 1]); }
-                else if constexpr (g == 2) { if (more2) { rd_group(fr[1], w1b); wait4(fr[0]); } else wait0(fr[0]); }
-                else if constexpr (g < 8) { rd_group(fr[(g + 1) & 1], w1b + (g - 2) * 4096); wait4(fr[g & 1]); }
-                else wait0(fr[g & 1]);
-                if constexpr (g < 3) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int mb = 0; mb < 2; ++mb)
-                            acc[mb][4 * g + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[g & 1][q], af[mb], acc[mb][4 * g + q], 0, 0, 0);
-                } else {
-                    step1_mma(fr[g & 1], g - 3);
-                }
-            }
-            // one DMA request behind each of the first six groups (50 cycles each: in the MFMAs' shadow, not ahead of them)
-            if constexpr (g < 3) {
-                if (kt + 2 < nkt)
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w2src[g] + (int64_t)(kt + 2) * FF_WS),
-                        (lds_ptr_t)(lds + ((kt + 2) % 3) * FF_WS + (3 * wave + g) * 1024), 16, 0, 0);
-            } else if constexpr (g < 6) {
-                if (kt + 4 < nkt)
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(w1src + (int64_t)(kt + 4) * FF_WS + (g - 3) * 1024),
-                        (lds_ptr_t)(lds + FF_W1_OFF + ((kt + 4) % 3) * FF_WS + (3 * wave + (g - 3)) * 1024), 16, 0, 0);
-            }
-            // the finish of block kt + 1, half behind each of the first two MFMA groups
-            if constexpr (g < 2) { if (more1) finish_half(g, bb[g]); }
-            FF_TICK(4 + g);
-        });
-        if (more2) { a1p[0] = a1n[0]; a1p[1] = a1n[1]; }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();                                               // the rings become the epilogue's scratch
-    FF_STAMP(6);
-
-    float* const prm = reinterpret_cast<float*>(lds + 4096 + 128 * LN_TS);
-    if (threadIdx.x < 3 * LN_N / 4) {
-        const int which = threadIdx.x / (LN_N / 4), o = (threadIdx.x % (LN_N / 4)) * 4;
-        const float* srcp = which == 0 ? b2 : which == 1 ? gamma : beta;
-        *reinterpret_cast<float4*>(prm + which * LN_N + o) = *reinterpret_cast<const float4*>(srcp + o);
-    }
-    // the residual is the tile of h the workgroup already holds (hq, step-1 layout): through LDS into the epilogue's layout
-    char* const park = lds + 4096;
-#pragma unroll
-    for (int sk = 0; sk < 12; ++sk)
-        *reinterpret_cast<uint4*>(park + (16 * wave + l15) * LN_TS + (32 * sk + 8 * g4) * 2) = __builtin_bit_cast(uint4, hq[sk]);
-    __syncthreads();
-    uint2 rres[2][12];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 12; ++nb)
-            rres[mb][nb] = *reinterpret_cast<const uint2*>(park + (32 * wm + 16 * mb + l15) * LN_TS + (192 * wn + 16 * nb + 4 * g4) * 2);
-    FF_STAMP(7);
-    ln_rows_epilogue(lds, prm, acc, rres, out, m0, M, eps, wm, wn, l15, g4);   // (its park writes come two barriers later)
-    FF_STAMP(8);
-#ifdef FF_TRACE
-    if (ff_slot >= 0 && lane == 0) ff_trace_buf[ff_slot][wave][14] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
-}
-
 // ---------------------------------------------------------------- fused FFN, second form (round 2): step 1 split over K
-// Same arithmetic as ffn_ln_kernel, other division of labour.  Cycle stamps of the first form (profiles/r02_ffn_trace.md):
+// Round 1's fused FFN (ffn_ln_kernel: step 1 by 16-row strips, rings of three per weight; retired in round 3, git history
+// and DESIGN.md 4.5 keep it) with another division of labour.  Cycle stamps of that first form (profiles/r02_ffn_trace.md):
 // a 3,640-cycle stage against 1,536 cycles of matrix pipe per SIMD -- 470 cycles without any MFMA between its two
 // barriers (fragment reads that could not be requested earlier, a vmcnt(0) hipcc put in front of a plain LDS load of
 // b1), six 4-MFMA groups whose fragments (24 ds_read_b128 per wave: every wave read the whole W1 block for its 16 rows)
@@ -1225,6 +974,9 @@ __global__ __launch_bounds__(512) void ffn_ln_kernel(const uint16_t* __restrict_
 #define F2_LDS_BYTES (F2_B1_OFF + 1536 * 4)
 #define F2_NKT 48                            // intermediate size 1536
 
+// FRONT: the attention output projection + residual + LayerNorm (what gemm_ln_kernel does for K = 384) runs first, on the
+// same 128 rows: h is then the layer's input (the residual of that LayerNorm), its result never goes to HBM -- it is
+// parked in LDS, becomes the h fragments of step 1 and the residual of the final LayerNorm.
 template <bool FRONT>
 __global__ __launch_bounds__(512) void ffn2_kernel(const uint16_t* __restrict__ h, const uint16_t* __restrict__ W1p,
         const float* __restrict__ b1, const uint16_t* __restrict__ W2p, const float* __restrict__ b2,
@@ -1955,7 +1707,7 @@ static int scratch_for_device(int device, void** out)
 
 struct LayerW {
     uint16_t *Wqkv, *Wo, *Wi, *Wd;                 // bf16 [out][in]
-    uint16_t *Wi_p = nullptr;                      // [I / 32][12][32][32] swizzled LDS image of Wi blocks (ffn_ln_kernel)
+    uint16_t *Wi_p = nullptr;                      // [I / 32][12][32][32] swizzled LDS image of Wi blocks (ffn2_kernel)
     uint16_t *Wo_p = nullptr, *Wd_p = nullptr;     // the same, [in / 32][out][32]: a 32-k stage of gemm_ln_kernel is one contiguous block
     float *bqkv, *bo, *bi, *bd, *g1, *b1, *g2, *b2; // fp32
     // ffn3_kernel (encoder_ffn3.hip): Wo, Wi, Wd as ONE stream of 108 fragment blocks in consumption order, and the layer's
@@ -2390,8 +2142,6 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     const bool fused_ffn = fused_ln && !ffn_off && I == 1536;
     static const bool front_off = getenv("MI_FFN_FRONT") && atoi(getenv("MI_FFN_FRONT")) == 0;
     const bool fused_front = fused_ffn && !front_off;
-    // MI_FFN2=0: the first form of the fused FFN (ffn_ln_kernel) instead of the K-split one (ffn2_kernel); read per call (A/B)
-    const bool ffn2 = !(getenv("MI_FFN2") && atoi(getenv("MI_FFN2")) == 0);
     // MI_FFN3=0: the round-2 kernel (ffn2_kernel) instead of the token-on-the-lane one (encoder_ffn3.hip); read per call (A/B)
     const bool ffn3 = fused_front && !(getenv("MI_FFN3") && atoi(getenv("MI_FFN3")) == 0);
     if (!capturing) MI_HIP(hipEventRecord(e->ev0, st));
@@ -2404,15 +2154,9 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
             MI_TRY(mi_launch_ffn3(st, ctx, h, lw.w3, lw.p3, c.layer_norm_eps, h, (int)T));
             continue;
         }
-        if (fused_front && ffn2) {
+        if (fused_front) {
             ffn2_kernel<true><<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T,
                                                                            ctx, lw.Wo_p, lw.bo, lw.g1, lw.b1);
-            continue;
-        }
-        if (fused_front) {
-            // attention output projection + LayerNorm + FFN + LayerNorm in one kernel per 128-row tile
-            ffn_ln_kernel<true><<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I,
-                                                                             ctx, lw.Wo_p, lw.bo, lw.g1, lw.b1);
             continue;
         }
         if (fused_ln) {
@@ -2422,14 +2166,9 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
             if (H <= 512) add_ln_kernel<1><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
             else add_ln_kernel<2><<<tok_grid, 256, 0, st>>>(tmp, T, H, lw.g1, lw.b1, c.layer_norm_eps, h);
         }
-        if (fused_ffn && ffn2) {
+        if (fused_ffn) {
             ffn2_kernel<false><<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T,
                                                                             nullptr, nullptr, nullptr, nullptr, nullptr);
-            continue;
-        }
-        if (fused_ffn) {
-            ffn_ln_kernel<false><<<(unsigned)((T + 127) / 128), 512, 0, st>>>(h, lw.Wi_p, lw.bi, lw.Wd_p, lw.bd, lw.g2, lw.b2, c.layer_norm_eps, h, (int)T, I,
-                                                                              nullptr, nullptr, nullptr, nullptr, nullptr);
             continue;
         }
         const bool mid_blocked = launch_gemm<EPI_GELU>(st, h, lw.Wi, lw.bi, nullptr, mid, (int)T, I, H, fused_ln);

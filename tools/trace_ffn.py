@@ -56,7 +56,7 @@ for sl in (0, 3):
     base = tk[sl, :, 1].min()
     for j, k in enumerate(ev):
         print(f"  {evn[j]:9s} " + " ".join(f"{int(x - base):6d}" for x in tk[sl, :, k]))
-if os.environ.get("MI_FFN2", "1") != "0":
+if True:   # (the round-1 kernel this used to switch to is retired)
     print("ffn2 stage timeline relative to the release of barrier alpha (rows: events, columns: waves 0..7), slots 0 and 3:")
     ev2 = [0, 1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 7, 8]
     evn2 = ["top", "at alpha", "past alpha", "g1 done", "g2 done", "at beta", "past beta", "g3 mfma'd", "+2 DMA", "g4 mfma'd", "+2 DMA", "g4 done", "g5 done"]
@@ -65,7 +65,7 @@ if os.environ.get("MI_FFN2", "1") != "0":
         for j, k in enumerate(ev2):
             print(f"  {evn2[j]:10s} " + " ".join(f"{int(x - base):6d}" for x in tk[sl, :, k]))
 
-if os.environ.get("MI_FFN2", "1") != "0":
+if True:   # (the round-1 kernel this used to switch to is retired)
     print("front GEMM: top of stage kt relative to the kernel's first stamp (slot 0, waves 0..7):")
     fr = t[0, :, 32:44]
     for kt in range(12):
