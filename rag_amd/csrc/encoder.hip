@@ -1741,22 +1741,28 @@ struct mi_encoder {
     float *word = nullptr, *pos = nullptr, *type0 = nullptr, *eg = nullptr, *eb = nullptr;
     std::vector<LayerW> layers;
     std::mutex mu;
-    // workspace
-    void* ws = nullptr;
-    size_t ws_bytes = 0;
-    // device staging of the host-pointer entry points: ids | types | mask, and the outputs
-    int32_t* d_io = nullptr;
-    float* d_out = nullptr;
-    size_t io_cap = 0, out_cap = 0;
+    // Two LANES: a call of several passes runs them alternately on two streams, each lane with its own workspace, staging
+    // and events, so one pass's memory-bound kernels (QKV projection, attention) and launch gaps run under the other's
+    // matrix-bound layer tail.  Lane 0 uses the caller's stream, lane 1 the encoder's own `st2`; a single pass is lane 0.
+    struct Lane {
+        void* ws = nullptr;             // activation workspace (grow-only)
+        size_t ws_bytes = 0;
+        int32_t* d_io = nullptr;        // device staging of the host-pointer entry points: ids | types | mask ...
+        float* d_out = nullptr;         // ... and the outputs
+        size_t io_cap = 0, out_cap = 0;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        // ev1 also orders the lane's workspace: it is recorded behind every pass, and a pass enqueued on ANOTHER stream than
+        // the lane's last one (a PyTorch stream through *_dev, then the ctx stream through a host entry point) waits on it first
+        hipStream_t last_st = nullptr;
+        bool have_last = false;
+    } ln[2];
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int last_lane = 0;                  // lane of the last pass (mi_encoder_last_time)
     // pinned host staging: two sets, so the host fills one while the GPU reads the other
     PinBuf pin_io[2], pin_out[2];
     hipEvent_t ev_pin[2] = {nullptr, nullptr};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    // ev1 also orders the shared workspace: it is recorded behind every pass, and a pass enqueued on ANOTHER stream than
-    // the last one (a PyTorch stream through *_dev, then the ctx stream through a host entry point) waits on it first
-    hipStream_t last_st = nullptr;
-    bool have_last = false;
     // cross-encoder head (mi_encoder_set_head): pooler W[H][H] b[H], classifier W[nl][H] b[nl], fp32 on device
     float* head = nullptr;
     int nlabels = 0;
@@ -1781,13 +1787,18 @@ static void encoder_free(mi_encoder* e)
     for (LayerW& lw : e->layers) { if (lw.bqkv) (void)hipFree(lw.bqkv); if (lw.w3) (void)hipFree(lw.w3); if (lw.p3) (void)hipFree(lw.p3); }
     if (e->blob) (void)hipFree(e->blob);
     if (e->wbf) (void)hipFree(e->wbf);
-    if (e->ws) (void)hipFree(e->ws);
-    if (e->d_io) (void)hipFree(e->d_io);
-    if (e->d_out) (void)hipFree(e->d_out);
+    for (auto& n : e->ln) {
+        if (n.ws) (void)hipFree(n.ws);
+        if (n.d_io) (void)hipFree(n.d_io);
+        if (n.d_out) (void)hipFree(n.d_out);
+        if (n.ev0) (void)hipEventDestroy(n.ev0);
+        if (n.ev1) (void)hipEventDestroy(n.ev1);
+    }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->st2) (void)hipStreamDestroy(e->st2);
     if (e->head) (void)hipFree(e->head);
     for (int s = 0; s < 2; ++s) { e->pin_io[s].release(); e->pin_out[s].release(); if (e->ev_pin[s]) (void)hipEventDestroy(e->ev_pin[s]); }
-    if (e->ev0) (void)hipEventDestroy(e->ev0);
-    if (e->ev1) (void)hipEventDestroy(e->ev1);
     delete e;
 }
 
@@ -1819,8 +1830,10 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
     ENC_HIP(hipMemcpyAsync(e->blob, blob_host, (size_t)want * sizeof(float), hipMemcpyHostToDevice, e->stream));
     const int64_t per_layer_w = (int64_t)4 * H * H + 2 * (int64_t)I * H + ((int64_t)H * H + 2 * (int64_t)H * I);   // + packed Wo, Wd, Wi
     ENC_HIP(hipMalloc((void**)&e->wbf, (size_t)(per_layer_w * cfg->num_hidden_layers) * sizeof(uint16_t)));
-    ENC_HIP(hipEventCreate(&e->ev0));
-    ENC_HIP(hipEventCreate(&e->ev1));
+    for (auto& n : e->ln) { ENC_HIP(hipEventCreate(&n.ev0)); ENC_HIP(hipEventCreate(&n.ev1)); }
+    ENC_HIP(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
+    ENC_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    ENC_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     for (int s = 0; s < 2; ++s) ENC_HIP(hipEventCreateWithFlags(&e->ev_pin[s], hipEventDisableTiming));
 
     float* p = e->blob;
@@ -2063,19 +2076,20 @@ static size_t encoder_ws_need(const mi_bert_config& c, int64_t T)
 }
 
 // The encoder's own grow-only workspace, sized for a pass over T tokens.
-static int ensure_ws(mi_encoder* e, int64_t T, hipStream_t st)
+static int ensure_ws(mi_encoder* e, int64_t T, hipStream_t st, int lane = 0)
 {
+    mi_encoder::Lane& n = e->ln[lane];
     const size_t need = encoder_ws_need(e->cfg, T);
-    if (need <= e->ws_bytes) return MI_OK;
-    if (e->ws) {
-        // the last pass may still be running on another stream than this one
-        if (e->have_last) MI_HIP(hipEventSynchronize(e->ev1));
+    if (need <= n.ws_bytes) return MI_OK;
+    if (n.ws) {
+        // the lane's last pass may still be running on another stream than this one
+        if (n.have_last) MI_HIP(hipEventSynchronize(n.ev1));
         MI_HIP(hipStreamSynchronize(st));
-        (void)hipFree(e->ws); e->ws = nullptr; e->ws_bytes = 0;
+        (void)hipFree(n.ws); n.ws = nullptr; n.ws_bytes = 0;
     }
-    hipError_t er = hipMalloc(&e->ws, need);
-    if (er != hipSuccess) { e->ws = nullptr; mi_set_error("encode: hipMalloc(%zu) for the workspace failed: %s", need, hipGetErrorString(er)); return MI_ERR_OOM; }
-    e->ws_bytes = need;
+    hipError_t er = hipMalloc(&n.ws, need);
+    if (er != hipSuccess) { n.ws = nullptr; mi_set_error("encode: hipMalloc(%zu) for the workspace failed: %s", need, hipGetErrorString(er)); return MI_ERR_OOM; }
+    n.ws_bytes = need;
     return MI_OK;
 }
 
@@ -2088,8 +2102,9 @@ static int ensure_ws(mi_encoder* e, int64_t T, hipStream_t st)
 // and types are unused -- no padding token is computed anywhere (mi_encoder_encode_ragged).
 static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids, const int32_t* types, const int32_t* mask,
                               float* out_emb, float* out_logits, hipStream_t st, void* ws_ext, size_t ws_ext_bytes,
-                              const int32_t* pos_ids = nullptr, const int32_t* seq_start = nullptr, int64_t T_packed = 0)
+                              const int32_t* pos_ids = nullptr, const int32_t* seq_start = nullptr, int64_t T_packed = 0, int lane = 0)
 {
+    mi_encoder::Lane& ln = e->ln[lane];
     const mi_bert_config& c = e->cfg;
     const int H = c.hidden_size, I = c.intermediate_size, NH = c.num_attention_heads;
     const int64_t T = seq_start ? T_packed : B * L;
@@ -2100,9 +2115,9 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap_status);
     const bool capturing = cap_status != hipStreamCaptureStatusNone;
-    // One workspace (and one `scratch` array) serves every pass of this encoder; passes on one stream serialise by themselves,
-    // a pass on another stream than the previous one waits for that one's end.
-    if (!capturing && e->have_last && e->last_st != st) MI_HIP(hipStreamWaitEvent(st, e->ev1, 0));
+    // One workspace per lane (and one `scratch` array) serves every pass of this encoder; passes on one stream serialise by
+    // themselves, a pass on another stream than the lane's previous one waits for that one's end.
+    if (!capturing && ln.have_last && ln.last_st != st) MI_HIP(hipStreamWaitEvent(st, ln.ev1, 0));
     void* wsp = nullptr;
     if (ws_ext) {
         if (need > ws_ext_bytes) {
@@ -2111,8 +2126,8 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
         }
         wsp = ws_ext;
     } else {
-        MI_TRY(ensure_ws(e, T, st));
-        wsp = e->ws;
+        MI_TRY(ensure_ws(e, T, st, lane));
+        wsp = ln.ws;
     }
     const size_t Tp = ((size_t)T + 127) / 128 * 128;
     uint16_t* h = (uint16_t*)wsp;
@@ -2144,7 +2159,7 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     const bool fused_front = fused_ffn && !front_off;
     // MI_FFN3=0: the round-2 kernel (ffn2_kernel) instead of the token-on-the-lane one (encoder_ffn3.hip); read per call (A/B)
     const bool ffn3 = fused_front && !(getenv("MI_FFN3") && atoi(getenv("MI_FFN3")) == 0);
-    if (!capturing) MI_HIP(hipEventRecord(e->ev0, st));
+    if (!capturing) MI_HIP(hipEventRecord(ln.ev0, st));
     if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, types, pos_ids, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, types, pos_ids, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     for (const LayerW& lw : e->layers) {
@@ -2192,10 +2207,11 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     }
     MI_HIP(hipGetLastError());
     if (!capturing) {
-        MI_HIP(hipEventRecord(e->ev1, st));
+        MI_HIP(hipEventRecord(ln.ev1, st));
         e->timed = true;
-        e->last_st = st;
-        e->have_last = true;
+        e->last_lane = lane;
+        ln.last_st = st;
+        ln.have_last = true;
     }
     e->st_seqs += B;
     e->st_tokens += T;
@@ -2210,16 +2226,39 @@ static int64_t encoder_pass_tokens()
     return pass_tokens > 0 ? pass_tokens : 65536;
 }
 
+// MI_ENC_LANES=1: every pass on the caller's stream, one after the other (read per call; A/B and debugging)
+static bool encoder_two_lanes()
+{
+    const char* s = getenv("MI_ENC_LANES");
+    return !(s && atoi(s) == 1);
+}
+
 // Device buffers [B][L] in passes of at most MI_ENC_PASS_TOKENS tokens.  Caller holds the mutex.
+// Two passes and more alternate between the encoder's two lanes: pass 2i on the caller's stream, pass 2i + 1 on st2, which
+// starts behind everything the caller's stream holds at this point (fork event) and which the caller's stream waits for at
+// the end (join event) -- to the caller the call is still one piece of work on its stream.
 static int encode_dev_locked(mi_encoder* e, int64_t B, int L, const int32_t* ids, const int32_t* types, const int32_t* mask,
                              float* out_emb, float* out_logits, hipStream_t st)
 {
     const int64_t bmax = (encoder_pass_tokens() / L) > 0 ? encoder_pass_tokens() / L : 1;
-    for (int64_t b0 = 0; b0 < B; b0 += bmax) {
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap_status);
+    const bool lanes = B > bmax && cap_status == hipStreamCaptureStatusNone && encoder_two_lanes();
+    if (lanes) {
+        MI_HIP(hipEventRecord(e->ev_fork, st));
+        MI_HIP(hipStreamWaitEvent(e->st2, e->ev_fork, 0));
+    }
+    int64_t pass = 0;
+    for (int64_t b0 = 0; b0 < B; b0 += bmax, ++pass) {
         const int64_t nb = (B - b0 < bmax) ? B - b0 : bmax;
+        const int lane = lanes ? (int)(pass & 1) : 0;
         MI_TRY(encode_pass_locked(e, nb, L, ids + b0 * L, types ? types + b0 * L : nullptr, mask + b0 * L,
                                   out_emb ? out_emb + b0 * e->cfg.hidden_size : nullptr,
-                                  out_logits ? out_logits + b0 * e->nlabels : nullptr, st, nullptr, 0));
+                                  out_logits ? out_logits + b0 * e->nlabels : nullptr, lane ? e->st2 : st, nullptr, 0, nullptr, nullptr, 0, lane));
+    }
+    if (lanes) {
+        MI_HIP(hipEventRecord(e->ev_join, e->st2));
+        MI_HIP(hipStreamWaitEvent(st, e->ev_join, 0));
     }
     return MI_OK;
 }
@@ -2277,24 +2316,25 @@ extern "C" int mi_encoder_classify_dev(mi_encoder* e, int64_t B, int L, const in
 
 // Device staging of the host-pointer entry points (caller holds the mutex): room for three [tokens] int32 planes
 // and `out_bytes` of results.
-static int ensure_io(mi_encoder* e, size_t tokens, size_t out_bytes, hipStream_t st)
+static int ensure_io(mi_encoder* e, size_t tokens, size_t out_bytes, hipStream_t st, int lane = 0)
 {
+    mi_encoder::Lane& n = e->ln[lane];
     const size_t nio = 3 * tokens * sizeof(int32_t);
-    if (nio > e->io_cap) {
+    if (nio > n.io_cap) {
         MI_HIP(hipStreamSynchronize(st));
-        if (e->d_io) (void)hipFree(e->d_io);
-        e->d_io = nullptr; e->io_cap = 0;
-        hipError_t er = hipMalloc((void**)&e->d_io, nio);
-        if (er != hipSuccess) { e->d_io = nullptr; mi_set_error("encode: hipMalloc(%zu) failed: %s", nio, hipGetErrorString(er)); return MI_ERR_OOM; }
-        e->io_cap = nio;
+        if (n.d_io) (void)hipFree(n.d_io);
+        n.d_io = nullptr; n.io_cap = 0;
+        hipError_t er = hipMalloc((void**)&n.d_io, nio);
+        if (er != hipSuccess) { n.d_io = nullptr; mi_set_error("encode: hipMalloc(%zu) failed: %s", nio, hipGetErrorString(er)); return MI_ERR_OOM; }
+        n.io_cap = nio;
     }
-    if (out_bytes > e->out_cap) {
+    if (out_bytes > n.out_cap) {
         MI_HIP(hipStreamSynchronize(st));
-        if (e->d_out) (void)hipFree(e->d_out);
-        e->d_out = nullptr; e->out_cap = 0;
-        hipError_t er = hipMalloc((void**)&e->d_out, out_bytes);
-        if (er != hipSuccess) { e->d_out = nullptr; mi_set_error("encode: hipMalloc(%zu) failed: %s", out_bytes, hipGetErrorString(er)); return MI_ERR_OOM; }
-        e->out_cap = out_bytes;
+        if (n.d_out) (void)hipFree(n.d_out);
+        n.d_out = nullptr; n.out_cap = 0;
+        hipError_t er = hipMalloc((void**)&n.d_out, out_bytes);
+        if (er != hipSuccess) { n.d_out = nullptr; mi_set_error("encode: hipMalloc(%zu) failed: %s", out_bytes, hipGetErrorString(er)); return MI_ERR_OOM; }
+        n.out_cap = out_bytes;
     }
     return MI_OK;
 }
@@ -2323,9 +2363,11 @@ static int encode_host(mi_encoder* e, const char* who, int64_t B, int L, const i
     const size_t width = logits ? (size_t)e->nlabels : (size_t)e->cfg.hidden_size;
     const size_t nout = (size_t)B * width * sizeof(float);
     MI_TRY(ensure_io(e, T, nout, st));
-    int32_t* d_ids = e->d_io;
-    int32_t* d_types = types ? e->d_io + T : nullptr;
-    int32_t* d_mask = e->d_io + 2 * T;
+    int32_t* const d_io = e->ln[0].d_io;
+    float* const d_out = e->ln[0].d_out;
+    int32_t* d_ids = d_io;
+    int32_t* d_types = types ? d_io + T : nullptr;
+    int32_t* d_mask = d_io + 2 * T;
     // small calls (a query, a few chunks) go through the pinned block: a pageable copy costs a staging hop and a
     // sync inside the runtime each way
     const bool pinned = 3 * nio <= ((size_t)1 << 20) && nout <= ((size_t)1 << 20);
@@ -2344,13 +2386,13 @@ static int encode_host(mi_encoder* e, const char* who, int64_t B, int L, const i
         MI_HIP(hipMemcpyAsync(d_mask, mask, nio, hipMemcpyHostToDevice, st));
         if (types) MI_HIP(hipMemcpyAsync(d_types, types, nio, hipMemcpyHostToDevice, st));
     }
-    MI_TRY(encode_dev_locked(e, B, L, d_ids, d_types, d_mask, logits ? nullptr : e->d_out, logits ? e->d_out : nullptr, st));
+    MI_TRY(encode_dev_locked(e, B, L, d_ids, d_types, d_mask, logits ? nullptr : d_out, logits ? d_out : nullptr, st));
     if (pinned) {
-        MI_HIP(hipMemcpyAsync(e->pin_out[0].p, e->d_out, nout, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipMemcpyAsync(e->pin_out[0].p, d_out, nout, hipMemcpyDeviceToHost, st));
         MI_HIP(hipStreamSynchronize(st));
         memcpy(out, e->pin_out[0].p, nout);
     } else {
-        MI_HIP(hipMemcpyAsync(out, e->d_out, nout, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipMemcpyAsync(out, d_out, nout, hipMemcpyDeviceToHost, st));
         MI_HIP(hipStreamSynchronize(st));
     }
     return MI_OK;
@@ -2462,8 +2504,18 @@ static int ragged_run(mi_encoder* e, const char* who, int64_t n, const int32_t* 
     // staging planes: ids [T] | mask or positions [T] | token types [T] (pairs only) | sequence starts [B + 1]
     const size_t io_elems = (logits ? 3 : 2) * Tmax + Bmax + 1;
     const size_t io_bytes = std::max(io_elems * sizeof(int32_t), (size_t)1 << 20), out_bytes = std::max(Bmax * H * sizeof(float), (size_t)1 << 20);
-    MI_TRY(ensure_io(e, (io_elems + 2) / 3, Bmax * H * sizeof(float), st));
-    MI_TRY(ensure_ws(e, (int64_t)Tmax, st));
+    // staging set s and lane s go together: set 0 on the encoder's stream, set 1 on st2 (which starts behind whatever the
+    // stream holds now); the host waits for each set's event before it reads its results, so nothing else joins them
+    const bool lanes = passes.size() > 1 && encoder_two_lanes();
+    hipStream_t lane_st[2] = {st, lanes ? e->st2 : st};
+    MI_TRY(ensure_io(e, (io_elems + 2) / 3, Bmax * H * sizeof(float), st, 0));
+    MI_TRY(ensure_ws(e, (int64_t)Tmax, st, 0));
+    if (lanes) {
+        MI_TRY(ensure_io(e, (io_elems + 2) / 3, Bmax * H * sizeof(float), e->st2, 1));
+        MI_TRY(ensure_ws(e, (int64_t)Tmax, e->st2, 1));
+        MI_HIP(hipEventRecord(e->ev_fork, st));
+        MI_HIP(hipStreamWaitEvent(e->st2, e->ev_fork, 0));
+    }
     for (int s = 0; s < 2 && s < (int)passes.size(); ++s) { MI_TRY(e->pin_io[s].ensure(io_bytes)); MI_TRY(e->pin_out[s].ensure(out_bytes)); }
     Pass inflight[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     auto unpack = [&](int s) -> int {                    // results of the pass staged in set s -> caller's rows
@@ -2489,7 +2541,10 @@ static int ragged_run(mi_encoder* e, const char* who, int64_t n, const int32_t* 
         int32_t* pmask = pid + T;                        // mask (padded) or positions (packed)
         int32_t* ptype = pmask + T;                      // pairs only
         int32_t* pstart = logits ? ptype + T : ptype;
-        int32_t* d_ids = e->d_io;
+        const int lane = lanes ? s : 0;
+        hipStream_t pst = lane_st[lane];
+        float* const d_out = e->ln[lane].d_out;
+        int32_t* d_ids = e->ln[lane].d_io;
         int32_t* d_mask = d_ids + T;
         int32_t* d_type = d_mask + T;
         int32_t* d_start = logits ? d_type + T : d_type;
@@ -2506,9 +2561,9 @@ static int ragged_run(mi_encoder* e, const char* who, int64_t n, const int32_t* 
                 at += (size_t)len;
             }
             pstart[B] = (int32_t)at;
-            MI_HIP(hipMemcpyAsync(d_ids, pid, ((logits ? 3 : 2) * T + (size_t)B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-            MI_TRY(encode_pass_locked(e, B, L, d_ids, logits ? d_type : nullptr, nullptr, logits ? nullptr : e->d_out, logits ? e->d_out : nullptr,
-                                      st, nullptr, 0, d_mask, d_start, (int64_t)T));
+            MI_HIP(hipMemcpyAsync(d_ids, pid, ((logits ? 3 : 2) * T + (size_t)B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, pst));
+            MI_TRY(encode_pass_locked(e, B, L, d_ids, logits ? d_type : nullptr, nullptr, logits ? nullptr : d_out, logits ? d_out : nullptr,
+                                      pst, nullptr, 0, d_mask, d_start, (int64_t)T, lane));
         } else {
             for (int64_t r = 0; r < B; ++r) {
                 const int64_t i = order[(size_t)(ps.first + r)];
@@ -2520,11 +2575,11 @@ static int ragged_run(mi_encoder* e, const char* who, int64_t n, const int32_t* 
                     memset(pmask + r * L + len, 0, (size_t)(L - len) * sizeof(int32_t));
                 }
             }
-            MI_HIP(hipMemcpyAsync(d_ids, pid, 2 * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
-            MI_TRY(encode_pass_locked(e, B, L, d_ids, nullptr, d_mask, e->d_out, nullptr, st, nullptr, 0));
+            MI_HIP(hipMemcpyAsync(d_ids, pid, 2 * T * sizeof(int32_t), hipMemcpyHostToDevice, pst));
+            MI_TRY(encode_pass_locked(e, B, L, d_ids, nullptr, d_mask, d_out, nullptr, pst, nullptr, 0, nullptr, nullptr, 0, lane));
         }
-        MI_HIP(hipMemcpyAsync(e->pin_out[s].p, e->d_out, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, st));
-        MI_HIP(hipEventRecord(e->ev_pin[s], st));
+        MI_HIP(hipMemcpyAsync(e->pin_out[s].p, d_out, (size_t)B * H * sizeof(float), hipMemcpyDeviceToHost, pst));
+        MI_HIP(hipEventRecord(e->ev_pin[s], pst));
         inflight[s] = ps;
     }
     // oldest first
@@ -2572,8 +2627,8 @@ extern "C" int mi_encoder_last_time(const mi_encoder* enc, float* out_ms)
     DeviceGuard guard(e->device);
     *out_ms = 0.0f;
     if (!e->timed) return MI_OK;
-    MI_HIP(hipEventSynchronize(e->ev1));
-    MI_HIP(hipEventElapsedTime(out_ms, e->ev0, e->ev1));
+    MI_HIP(hipEventSynchronize(e->ln[e->last_lane].ev1));
+    MI_HIP(hipEventElapsedTime(out_ms, e->ln[e->last_lane].ev0, e->ln[e->last_lane].ev1));
     return MI_OK;
 }
 

@@ -246,3 +246,50 @@ def test_slab_pipeline_equals_the_one_shot_call(tmp_path):
     E3 = multi.embed_documents_array(texts)
     assert E3.shape == E1.shape and np.all(_cos_err(E1, E3) < 5e-5), _cos_err(E1, E3).max()
     assert sum(e.stats()["sequences"] for e in multi.encoders) == 1500 and all(e.stats()["sequences"] > 0 for e in multi.encoders)
+
+
+def test_two_lanes_equal_one_lane_and_stay_ordered(oracle_mod, monkeypatch):
+    """A call of several passes alternates them between the encoder's two lanes (own stream, workspace and staging each).
+    Same bits as the one-lane run (MI_ENC_LANES=1, read per call) for the device-pointer and the host-pointer entry
+    points, rows against the oracle, and the call stays one piece of work on the caller's stream: a consumer enqueued on
+    PyTorch's stream right behind it -- no synchronisation -- reads finished rows of BOTH lanes."""
+    import torch
+    from rag_amd._capi import BertConfig
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import random_blob
+    vals = (1000, 384, 2, 12, 1536, 512, 2, 1e-12, 1)
+    cfg, ocfg = BertConfig(*vals), oracle_mod.BertConfig(*vals)
+    blob = random_blob(cfg, seed=21, init_range=0.05)
+    enc = Encoder(cfg, blob)
+    monkeypatch.setenv("MI_ENC_PASS_TOKENS", "16384")       # read once per process: only effective if nothing encoded before
+    rng = np.random.default_rng(5)
+    B, L = 5 * 512 + 100, 128                               # several passes whatever the pass size, a ragged last one
+    ids = rng.integers(0, 1000, size=(B, L)).astype(np.int32)
+    mask = np.ones_like(ids)
+    mask[7, 50:] = 0
+    rows = [0, 7, 511, 512, 1300, B - 1]
+    want = oracle_mod.encode(ocfg, blob, ids[rows], mask[rows])
+    ids_t, mask_t = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    torch.cuda.synchronize()
+    passes0 = sum(enc.stats()[k] for k in ("bulk_passes", "latency_passes"))
+    got, sums = {}, {}
+    for lanes in ("2", "1"):
+        monkeypatch.setenv("MI_ENC_LANES", lanes)
+        E = enc.encode_ids_torch(ids_t, mask_t)
+        sums[lanes] = E.sum(dim=1)                            # consumer on PyTorch's stream, no sync in between
+        torch.cuda.synchronize()
+        got[lanes] = E.cpu().numpy()
+        assert np.allclose(sums[lanes].cpu().numpy(), got[lanes].sum(axis=1), rtol=0, atol=1e-4)
+        assert np.all(_cos_err(got[lanes][rows], want) < TOL)
+        Eh = enc.encode_ids(ids[:1200], mask[:1200])        # host pointers: the padded entry point, lanes inside
+        assert np.array_equal(Eh, got[lanes][:1200])
+    assert np.array_equal(got["2"], got["1"])
+    assert sum(enc.stats()[k] for k in ("bulk_passes", "latency_passes")) - passes0 >= 8       # it really was several passes per call
+    lens = rng.integers(1, L + 1, size=3000)
+    flat = np.concatenate([ids[i % B, :n] for i, n in enumerate(lens)]).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    R = {}
+    for lanes in ("2", "1"):
+        monkeypatch.setenv("MI_ENC_LANES", lanes)
+        R[lanes] = enc.encode_ragged(flat, off, max_len=L)
+    assert np.array_equal(R["2"], R["1"])
