@@ -1,6 +1,6 @@
 """Randomised parity soak of the cross-encoder path: random numbers of (query, passage) pairs of random lengths through
 mi_encoder_classify_ragged (packed passes, both kernel families, random pass caps, 1 .. 3 labels) against the CPU oracle,
-allowance as in tests/test_rerank_gpu.py (16 x 2^-9 x mean |pooler row| x max |classifier row|).  MiniLM-shaped layers, two
+allowance as in tests/test_rerank_gpu.py (20 x 2^-9 x mean |pooler row| x max |classifier row|).  MiniLM-shaped layers, two
 of them.  Runs for FUZZ_SECONDS (default 120); prints progress and one summary line; status 1 on a violation.
 Test infrastructure (imports oracle/): not part of the product."""
 import json, os, sys, time
@@ -32,7 +32,7 @@ while time.time() < t_end:
         e.set_head(*h)
         encs[nl] = (e, h)
     enc, head = encs[nl]
-    tol = 16.0 * 2.0 ** -9 * float(np.linalg.norm(head[0], axis=1).mean()) * float(np.linalg.norm(head[2], axis=1).max())
+    tol = 20.0 * 2.0 ** -9 * float(np.linalg.norm(head[0], axis=1).mean()) * float(np.linalg.norm(head[2], axis=1).max())
     n = int(rng.integers(1, 70))
     hi = int(rng.choice([6, 40, 130, 300, 512]))
     lens = rng.integers(1, hi + 1, size=n)

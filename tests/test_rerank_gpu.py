@@ -7,10 +7,11 @@ noise away; a logit is ONE scalar read off ONE token ([CLS]), so the bar here is
 model of the path: the hidden state is bf16 between kernels (relative rounding 2^-9 per element of a LayerNorm
 output of unit scale, fp32 accumulation everywhere), the head is fp32, hence
     |logit error| ~ 2^-9 * |pooler row|_2 * |cls_w|_2   (one standard deviation, tanh' <= 1).
-`_logit_tol` allows 16 of those.  It is PINNED FROM MEASUREMENT, not derived: the worst error seen anywhere -- the three
-cases below (5.3e-3 / 2.1e-2 / 2.6e-2) and the randomised soak (tests/soak_rerank.py, 24,671 pairs in round 2, re-run in
-round 3 with the fused layer tail: profiles/r03_fuzz.jsonl) -- is 6.9 of those units, so the allowance holds a margin of
-2.3 x over the worst case on record (the round-2 allowance of 8 units was filled to 86 %).  Carrying the last layer's
+`_logit_tol` allows 20 of those.  It is PINNED FROM MEASUREMENT, not derived: the worst error seen anywhere -- the three
+cases below (5.3e-3 / 2.1e-2 / 2.6e-2) and the randomised soaks (tests/soak_rerank.py: 24,671 pairs in round 2, worst 6.9
+units; 48,087 pairs in round 3 with the fused layer tail, worst 8.0 units: profiles/r03_fuzz.jsonl) -- is 8.0 of those units,
+so the allowance holds a margin of 2.5 x over the worst case on record (the round-2 allowance of 8 units was filled to 86 %).
+Carrying the last layer's
 [CLS] row to the head in fp32 would remove ONE of the 2 x layers bf16 roundings that row has been through (the noise adds
 in quadrature: ~4 % for six layers), so the head reads the bf16 row every other consumer reads.  The property that matters
 downstream is held too: the same candidate order wherever two reference scores differ by more than twice the allowance."""
@@ -24,7 +25,7 @@ XGOLD = os.path.join(os.path.dirname(__file__), "golden", "cross_encoder_small.n
 
 
 def _logit_tol(pooler_w, cls_w):
-    return 16.0 * 2.0 ** -9 * float(np.linalg.norm(pooler_w, axis=1).mean()) * float(np.linalg.norm(cls_w, axis=1).max())
+    return 20.0 * 2.0 ** -9 * float(np.linalg.norm(pooler_w, axis=1).mean()) * float(np.linalg.norm(cls_w, axis=1).max())
 
 
 def _same_order(got, want, tol):
