@@ -364,16 +364,26 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
     lds_cfloat* const p_b2 = pl + 3 * F3_H, * const p_g2 = pl + 4 * F3_H, * const p_be2 = pl + 5 * F3_H;
     lds_cfloat* const p_b1 = pl + 6 * F3_H;
 
+    // ctx^T of a tile (blocked [tile][12][128][32]: two k-steps are one 64-B row of a block): requested for the first tile
+    // here, for every later one behind the FFN loop of the tile before -- its 96 registers are free from the last FFN1 block
+    // on, and the requests run under LayerNorm 2 and the row stores instead of adding to the next tile's load burst.
+    bf16x8 cf[24];                                                 // ctx^T, later h1^T: B fragments, k-step s (16 channels)
+    auto load_ctx = [&](int tile) __attribute__((always_inline)) {
+        const int tl = 32 * wave + r;                              // token within the tile (ctx is padded to whole tiles)
+#pragma unroll
+        for (int s = 0; s < 24; ++s)
+            cf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ctx + (((size_t)tile * 12 + (s >> 1)) * 128 + tl) * 32 + 16 * (s & 1) + 8 * h));
+    };
+#ifndef F3_NO_CTX_AHEAD
+    if ((int)blockIdx.x < ntiles) load_ctx(blockIdx.x);
+#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * 128 + 32 * wave;
         F3_STAMP(0);
-        bf16x8 cf[24];                                             // ctx^T, later h1^T: B fragments, k-step s (16 channels)
-        // ---- token loads: ctx (blocked [tile][12][128][32]: two k-steps are one 64-B row of a block) and the residual row;
-        // the accumulators start at bo + h.  A lane loads 8 consecutive channels of its token (channels 16 s + 8 h ..); the
+        // ---- token loads: the residual row (ctx^T is on its way already); the accumulators start at bo + h.  A lane loads 8 consecutive channels of its token (channels 16 s + 8 h ..); the
         // swap hands each lane of the pair its 4 + 4.  The parameter reads run one step ahead of their use (pr[]): a lone
         // wave that reads LDS and waits, 48 times, pays the LDS latency 48 times.
         {
-            const int tl = 32 * wave + r;                          // token within the tile (ctx is padded to whole tiles)
             int tok = m0 + r; if (tok > M - 1) tok = M - 1;
             const uint16_t* const hrow = hin + (size_t)tok * F3_H + 8 * h;
             f32x4 pr[2][2];
@@ -388,9 +398,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
 #pragma unroll
                 for (int i = 0; i < 12; ++i) hv[i] = *reinterpret_cast<const uint4*>(hrow + 16 * (S0 + i));
                 if constexpr (S0 == 0) {
-#pragma unroll
-                    for (int s = 0; s < 24; ++s)
-                        cf[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ctx + (((size_t)tile * 12 + (s >> 1)) * 128 + tl) * 32 + 16 * (s & 1) + 8 * h));
+#ifdef F3_NO_CTX_AHEAD
+                    load_ctx(tile);
+#endif
                     ld(IC<0>{});
                 }
                 static_for<12>([&](auto Ic) {
@@ -605,6 +615,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256))) void 
         ffn2(Xb, IC<0>{}, IC<0>{}, Xa, -1, IC<1>{});               // block 47
         F3_ACC_SETTLE();
         F3_STAMP(4);
+#ifndef F3_NO_CTX_AHEAD
+        if (tile + (int)gridDim.x < ntiles) load_ctx(tile + (int)gridDim.x);
+#endif
 
         // ---- LayerNorm 2 and the row out: 16 bytes per lane and k-step (the swap of the loads, backwards), 32 contiguous
         // bytes per row and instruction
