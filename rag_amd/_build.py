@@ -74,6 +74,33 @@ def audit_ffn3(workdir: str | None = None, extra_flags=()) -> None:
         raise RuntimeError(f"encoder_ffn3.hip: vector register spills {spills}")
 
 
+# Files whose kernels (names containing the substring) must compile without a single spilled register or byte of scratch:
+# the scan kernels sit at 250-256 VGPRs with two waves per SIMD, and one more live value makes hipcc spill ~200 registers --
+# the kernel stays correct and gets 2.3 x slower at 512 queries (a scratch reload in the loop waits for vmcnt(0), which drains
+# the LDS-DMA prefetch).  Measured the hard way in round 3.
+NO_SPILL = {"search_mfma.hip": "mfma_scan_kernel"}
+
+
+def audit_spills(remarks: str, name_part: str):
+    """Parses hipcc -Rpass-analysis=kernel-resource-usage output; returns [(kernel, spilled VGPRs, scratch bytes)] of the
+    offenders among the kernels whose mangled name contains `name_part` (raises if none was reported at all)."""
+    import re
+    blocks = re.split(r"remark: Function Name: ", remarks)[1:]
+    seen, bad = 0, []
+    for b in blocks:
+        name = b.split()[0]
+        if name_part not in name:
+            continue
+        seen += 1
+        sp = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+        sc = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        if sp or sc:
+            bad.append((name, sp, sc))
+    if not seen:
+        raise RuntimeError(f"no resource report for kernels named *{name_part}* (hipcc output format changed?)")
+    return bad
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -91,7 +118,21 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     def run(cmd):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+        src = next((os.path.basename(a) for a in cmd if a.endswith(".hip")), None)
+        if src not in NO_SPILL:
+            subprocess.check_call(cmd)
+            return
+        # the compiler's own resource report of every kernel in the file, taken from the build that is linked
+        r = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr)
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        bad = audit_spills(r.stderr, NO_SPILL[src])
+        if bad:
+            obj = cmd[cmd.index("-o") + 1]
+            if os.path.exists(obj):
+                os.remove(obj)                                         # never link such a build
+            raise RuntimeError(f"{src}: kernels with register spills or scratch memory: {bad}")
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:
