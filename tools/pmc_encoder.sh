@@ -1,6 +1,7 @@
 # PMC passes over one bulk-embedding call (4096 chunks x 256 tokens, MiniLM-L6), one counter group per run.
 # usage (on the GPU box): bash tools/pmc_encoder.sh   -> gpurun_out/pmc_enc/p<i>/
 set -e
+export MI_ENC_LANES=1   # one lane: kernels of different passes must not overlap while counters are attributed per dispatch
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/pmc_enc
 cd /tmp && export TMPDIR=/tmp

@@ -16,7 +16,8 @@ run() {   # name, bench args...
     find $out/${tag}_$name -name '*kernel_stats.csv' -exec cp {} $out/${tag}_${name}_kernel_stats.csv \;
 }
 run bench
-run embed --embed-only --no-cpu-baseline
+MI_ENC_LANES=1 run embed --embed-only --no-cpu-baseline      # one lane: per-kernel durations (two lanes overlap kernels of different passes)
+run embed_lanes --embed-only --no-cpu-baseline
 run scan768 --rows 50000000 --dim 768 --k 100 --no-cpu-baseline --embed-chunks 0
 timeout -k 10 300 python3 $root/bench.py > $out/${tag}_bench_plain.json 2> $out/${tag}_bench_plain.err
 tail -n 1 $out/${tag}_bench_plain.json
