@@ -1150,12 +1150,13 @@ int mi_mfma_make_plan(int64_t n, int d_pad, int64_t nq, int k, mi_mfma_plan* pla
     // at least ~32 tiles per slice so the running thresholds have time to tighten; with one or two
     // query tiles the scan is a latency problem instead (200,000 rows x 1 query: 48 slices took
     // 293 us on 48 CUs), so there 8 tiles per slice are enough - the lists are rescored exactly anyway
-    // (1M x 384 x 1,000 queries with the threshold seed below, 120 / 192 / 256 slices: scan 0.82 / 0.72 / 0.69 ms, wall
-    // 0.95 / 0.91 / 0.89 -- a workgroup's start-up is paid once per round of 256 workgroups either way, shorter slices
-    // balance the last round better: tools/config2_sweep.py)
-    // (30, not 32: 1M rows / 256 slices is 30.5 tiles, and 4 query tiles x 256 slices fill whole rounds of 256 workgroups)
-    const int min_tiles = (nqt <= 2) ? 8 : 30;
-    while (ns > 8 && n / ns < (int64_t)min_tiles * MF_TILE_R) ns -= 8;
+    // (1M x 384 x 1,000 queries with the threshold seed below, warm clocks, 64 / 128 / 192 / 256 slices: scan 0.64 / 0.65 /
+    // 0.65 / 0.66 ms, wall 0.78 / 0.78 / 0.85 / 0.85 -- the scan does not care, the finish pays per slice and per group of
+    // 128 slices; 60 tiles stop the search at 128 slices there, whole rounds of 256 workgroups with four query tiles:
+    // tools/config2_sweep.py)
+    const int min_tiles = (nqt <= 2) ? 8 : 60;
+    // (never below one workgroup per CU for the sake of longer slices, unless the slices would be shorter than 8 tiles)
+    while (ns > 8 && n / ns < (int64_t)min_tiles * MF_TILE_R && ((int64_t)(ns - 8) * nqt >= 256 || n / ns < 8 * MF_TILE_R)) ns -= 8;
     if (ns < 8) ns = 8;
     if (const char* e = getenv("MI_MFMA_NS")) {
         const int v = atoi(e) / 8 * 8;
