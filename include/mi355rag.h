@@ -300,15 +300,24 @@ int  mi_encoder_encode_dev_noalloc(mi_encoder* enc, int64_t B, int L, const int3
 int  mi_encoder_last_time(const mi_encoder* enc, float* out_ms);
 
 /* ---- host text path: WordPiece tokenizer (pure host code, no GPU call)
- * Replaces, for ASCII input, the tokenizer advanced_rag.py:104-107 reaches through HuggingFaceEmbeddings ->
+ * Replaces the tokenizer advanced_rag.py:104-107 reaches through HuggingFaceEmbeddings ->
  * sentence-transformers -> `tokenizers` (BertNormalizer, BertPreTokenizer, WordPiece, [CLS] .. [SEP], truncation):
  * embed_documents (advanced_rag.py:295) from List[str] was bound by it.  vocab: the bytes of vocab.txt (one entry per
  * line, line number = id).  encode_batch: text i = text[text_offsets[i] .. text_offsets[i + 1]); out_ids holds n rows of
  * max_len ids, row i filled with out_lens[i] of them ([CLS] pieces [SEP], cut to max_len); out_lens[i] = -1 marks a text
- * with a byte >= 0x80 or a spelled-out special token ("[" A-Z+ "]"), which is left to the reference tokenizer.  n_threads <= 0:
- * OMP_NUM_THREADS, else min(16, cores). */
+ * that is left to the reference tokenizer: one with a spelled-out special token ("[" A-Z+ "]"), and non-ASCII text while no
+ * Unicode table is set, or with a character outside the table / of class "decline", or malformed UTF-8.  n_threads <= 0:
+ * OMP_NUM_THREADS, else min(16, cores).
+ * set_unicode: per-code-point tables for UTF-8 text, code points [0, n_codepoints).  map[cp] says what the normalizer
+ * (clean-up, CJK spacing, accent stripping, lower-casing: all per character in BertNormalizer) turns an INPUT character
+ * into: 0xFFFFFFFF = itself, else (offset into pool << 8) | number of bytes of UTF-8 there (0 bytes = the character is
+ * dropped).  cls[cp] says what an OUTPUT character is to BertPreTokenizer: 0 word character, 1 space, 2 punctuation (a
+ * word of its own), 3 decline (the whole text is handed back with -1).  The tables are copied; n_codepoints = 0 removes
+ * them.  Not to be called while encode_batch runs on the same tokenizer. */
 typedef struct mi_wordpiece mi_wordpiece;
 int  mi_wordpiece_create(const char* vocab, int64_t vocab_bytes, int lowercase, mi_wordpiece** out);
+int  mi_wordpiece_set_unicode(mi_wordpiece* wp, int64_t n_codepoints, const uint8_t* cls, const uint32_t* map,
+                              const char* pool, int64_t pool_bytes);
 void mi_wordpiece_destroy(mi_wordpiece* wp);
 int  mi_wordpiece_encode_batch(const mi_wordpiece* wp, const char* text, const int64_t* text_offsets, int64_t n,
                                int max_len, int n_threads, int32_t* out_ids, int64_t* out_lens);

@@ -108,6 +108,7 @@ SYMBOLS = {
     "mi_encoder_stats": (_i32, [_vp, ctypes.POINTER(ctypes.c_int64)]),
     "mi_encoder_last_time": (_i32, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "mi_wordpiece_create": (_i32, [ctypes.c_char_p, _i64, _i32, _pp]),
+    "mi_wordpiece_set_unicode": (_i32, [_vp, _i64, _vp, _vp, ctypes.c_char_p, _i64]),
     "mi_wordpiece_destroy": (None, [_vp]),
     "mi_wordpiece_encode_batch": (_i32, [_vp, ctypes.c_char_p, _vp, _i64, _i32, _i32, _vp, _vp]),
 }

@@ -10,10 +10,16 @@
 //   WordPiece  per word, greedy longest match first; pieces after the first carry the prefix "##"; a word of more than 100
 //              characters, or one with a stretch no vocabulary entry matches, is ONE [UNK]
 //   frame      [CLS] pieces[: max_len - 2] [SEP]
-// A text with any byte >= 0x80 is NOT handled here (accent stripping, CJK spacing and Unicode categories stay with the
-// reference library), nor is one that spells a special token ("[SEP]", "[MASK]": any "[" A-Z+ "]"), which the reference
-// matches in the raw string: its length comes back as -1 and the caller tokenises it there.  Parity with `tokenizers` on ASCII
-// text is held by tests/test_wordpiece.py.
+// Text with bytes >= 0x80 (UTF-8) goes the same way once mi_wordpiece_set_unicode has handed over per-code-point tables:
+// `map` (what one input character becomes after clean-up, CJK spacing, accent stripping and lower-casing: itself, nothing,
+// or up to a few characters) and `cls` (what an OUTPUT character is to the splitter: word character, space, punctuation, or
+// "decline").  Both steps of the reference are per character, so tables reproduce them exactly; the caller fills them from
+// the reference library's own normalizer and pre-tokenizer (rag_amd/embeddings.py), which keeps Unicode versions out of
+// this file.  Words are then matched at character boundaries and the 100-character rule counts characters.
+// Left to the reference library (the text's length comes back as -1 and the caller tokenises it there): non-ASCII text while
+// no table is set, a character beyond the table or of class "decline", malformed UTF-8, and any text that spells a special
+// token ("[SEP]", "[MASK]": any "[" A-Z+ "]"), which the reference matches in the raw string.  Parity with `tokenizers` is
+// held by tests/test_wordpiece.py.
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -33,6 +39,10 @@ struct mi_wordpiece {
     int32_t unk = -1, cls = -1, sep = -1;
     int lowercase = 1;
     int max_chars = 100;
+    // Unicode tables (mi_wordpiece_set_unicode); empty = ASCII only
+    std::vector<uint8_t> ucls;           // per OUTPUT code point: 0 word character, 1 space, 2 punctuation, 3 decline
+    std::vector<uint32_t> umap;          // per INPUT code point: 0xFFFFFFFF itself, else (offset into upool << 8) | bytes
+    std::string upool;
 };
 
 namespace {
@@ -78,18 +88,117 @@ inline void word_pieces(const mi_wordpiece* w, const char* s, size_t L, std::vec
     }
 }
 
-// -1: the text holds a byte >= 0x80; else the number of ids written to out (<= max_len)
-int64_t encode_one(const mi_wordpiece* w, const char* t, size_t n, int max_len, std::vector<int32_t>& tmp, std::string& word, int32_t* out, uint64_t hcont0)
+// the same for a word of UTF-8 text: ends[i] = byte offset just past character i (nc characters)
+inline void word_pieces_u(const mi_wordpiece* w, const char* s, const uint32_t* ends, size_t nc, std::vector<int32_t>& out, uint64_t hcont0)
 {
+    if ((int)nc > w->max_chars) { out.push_back(w->unk); return; }
+    const size_t mark = out.size();
+    uint64_t hs[128];
+    size_t start = 0;                                          // in characters
+    while (start < nc) {
+        const size_t b0 = start ? ends[start - 1] : 0;
+        uint64_t h = start ? hcont0 : FNV0;
+        size_t b = b0;
+        for (size_t e = start; e < nc; ++e) { for (; b < ends[e]; ++b) h = fnv(h, (unsigned char)s[b]); hs[e - start] = h; }
+        int32_t got = -1;
+        size_t end = nc;
+        for (; end > start; --end) {
+            got = find(w, hs[end - start - 1], s + b0, ends[end - 1] - b0, start > 0);
+            if (got >= 0) break;
+        }
+        if (got < 0) { out.resize(mark); out.push_back(w->unk); return; }
+        out.push_back(got);
+        start = end;
+    }
+}
+
+// one UTF-8 character at t[i..n): its code point and length, or 0 length if malformed (overlong, surrogate, > 0x10FFFF, cut short)
+inline uint32_t utf8_at(const unsigned char* t, size_t i, size_t n, uint32_t* len)
+{
+    const uint32_t c = t[i];
+    if (c < 0x80) { *len = 1; return c; }
+    uint32_t need, cp, lo;
+    if ((c & 0xE0) == 0xC0) { need = 1; cp = c & 0x1F; lo = 0x80; }
+    else if ((c & 0xF0) == 0xE0) { need = 2; cp = c & 0x0F; lo = 0x800; }
+    else if ((c & 0xF8) == 0xF0) { need = 3; cp = c & 0x07; lo = 0x10000; }
+    else { *len = 0; return 0; }
+    if (i + need >= n) { *len = 0; return 0; }                 // cut short
+    for (uint32_t k = 1; k <= need; ++k) {
+        const uint32_t x = t[i + k];
+        if ((x & 0xC0) != 0x80) { *len = 0; return 0; }
+        cp = (cp << 6) | (x & 0x3F);
+    }
+    if (cp < lo || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) { *len = 0; return 0; }
+    *len = need + 1;
+    return cp;
+}
+
+struct Scratch { std::vector<int32_t> tmp; std::string word; std::vector<uint32_t> ends; };
+
+// UTF-8 text through the tables; -1 = declined
+int64_t encode_one_u(const mi_wordpiece* w, const char* t, size_t n, int max_len, Scratch& sc, int32_t* out, uint64_t hcont0)
+{
+    const unsigned char* u = (const unsigned char*)t;
+    const size_t ncp = w->umap.size();
+    std::vector<int32_t>& tmp = sc.tmp;
+    std::string& word = sc.word;
+    std::vector<uint32_t>& ends = sc.ends;
+    tmp.clear(); word.clear(); ends.clear();
+    const size_t budget = max_len >= 2 ? (size_t)max_len - 2 : 0;
+    auto flush = [&]() { if (!ends.empty()) { word_pieces_u(w, word.data(), ends.data(), ends.size(), tmp, hcont0); word.clear(); ends.clear(); } };
+    // one OUTPUT character (bytes p[0:len), code point cp) into the splitter; false = decline
+    auto feed = [&](uint32_t cp, const char* p, uint32_t len) -> bool {
+        if (cp >= ncp) return false;
+        switch (w->ucls[cp]) {
+        case 0: word.append(p, len); ends.push_back((uint32_t)word.size()); return true;
+        case 1: flush(); return true;
+        case 2: { flush(); const uint32_t e = len; word_pieces_u(w, p, &e, 1, tmp, hcont0); return true; }
+        default: return false;
+        }
+    };
+    for (size_t i = 0; i < n && tmp.size() < budget;) {
+        uint32_t len;
+        const uint32_t cp = utf8_at(u, i, n, &len);
+        if (len == 0 || cp >= ncp) return -1;
+        const uint32_t m = w->umap[cp];
+        if (m == 0xFFFFFFFFu) { if (!feed(cp, t + i, len)) return -1; }
+        else {
+            const char* p = w->upool.data() + (m >> 8);
+            const size_t pn = m & 0xFF;
+            for (size_t k = 0; k < pn;) {                        // (validated when the tables were set)
+                uint32_t l2;
+                const uint32_t c2 = utf8_at((const unsigned char*)p, k, pn, &l2);
+                if (!feed(c2, p + k, l2)) return -1;
+                k += l2;
+            }
+        }
+        i += len;
+    }
+    if (tmp.size() < budget) flush();
+    const size_t m = std::min(tmp.size(), budget);
+    int64_t k = 0;
+    if (max_len >= 1) out[k++] = w->cls;
+    for (size_t i = 0; i < m; ++i) out[k++] = tmp[i];
+    if (max_len >= 2) out[k++] = w->sep;
+    return k;
+}
+
+// -1: declined (see the header of this file); else the number of ids written to out (<= max_len)
+int64_t encode_one(const mi_wordpiece* w, const char* t, size_t n, int max_len, Scratch& sc, int32_t* out, uint64_t hcont0)
+{
+    std::vector<int32_t>& tmp = sc.tmp;
+    std::string& word = sc.word;
+    bool high = false;
     for (size_t i = 0; i < n; ++i) {
         const unsigned char c = (unsigned char)t[i];
-        if (c >= 0x80) return -1;
+        if (c >= 0x80) { high = true; continue; }
         if (c == '[') {                                        // "[SEP]", "[MASK]", ... in the text: the reference matches its special
             size_t j = i + 1;                                  // tokens in the raw string before anything else -- leave the text to it
             while (j < n && t[j] >= 'A' && t[j] <= 'Z') ++j;
             if (j > i + 1 && j < n && t[j] == ']') return -1;
         }
     }
+    if (high) return w->umap.empty() ? -1 : encode_one_u(w, t, n, max_len, sc, out, hcont0);
     tmp.clear();
     word.clear();
     const size_t budget = max_len >= 2 ? (size_t)max_len - 2 : 0;
@@ -156,6 +265,32 @@ extern "C" int mi_wordpiece_create(const char* vocab, int64_t vocab_bytes, int l
     return MI_OK;
 }
 
+extern "C" int mi_wordpiece_set_unicode(mi_wordpiece* w, int64_t n_codepoints, const uint8_t* cls, const uint32_t* map,
+                                        const char* pool, int64_t pool_bytes)
+{
+    MI_REQUIRE(w, "mi_wordpiece_set_unicode: NULL tokenizer");
+    if (n_codepoints == 0) { w->ucls.clear(); w->umap.clear(); w->upool.clear(); return MI_OK; }
+    MI_REQUIRE(cls && map && n_codepoints >= 128 && n_codepoints <= 0x110000 && pool_bytes >= 0 && pool_bytes < (1 << 24) && (pool || pool_bytes == 0),
+               "mi_wordpiece_set_unicode: tables out of range (128 <= n_codepoints <= 0x110000, pool < 16 MiB)");
+    for (int64_t cp = 0; cp < n_codepoints; ++cp) {
+        MI_REQUIRE(cls[cp] <= 3, "mi_wordpiece_set_unicode: cls[%lld] = %d is no class", (long long)cp, (int)cls[cp]);
+        const uint32_t m = map[cp];
+        if (m == 0xFFFFFFFFu) continue;
+        const size_t off = m >> 8, len = m & 0xFF;
+        MI_REQUIRE((int64_t)(off + len) <= pool_bytes, "mi_wordpiece_set_unicode: map[%lld] points past the pool", (long long)cp);
+        for (size_t k = 0; k < len;) {
+            uint32_t l2;
+            const uint32_t c2 = utf8_at((const unsigned char*)pool + off, k, len, &l2);
+            MI_REQUIRE(l2 != 0 && (int64_t)c2 < n_codepoints, "mi_wordpiece_set_unicode: map[%lld] is not UTF-8 of characters inside the table", (long long)cp);
+            k += l2;
+        }
+    }
+    w->ucls.assign(cls, cls + n_codepoints);
+    w->umap.assign(map, map + n_codepoints);
+    w->upool.assign(pool ? pool : "", (size_t)pool_bytes);
+    return MI_OK;
+}
+
 extern "C" void mi_wordpiece_destroy(mi_wordpiece* w) { delete w; }
 
 extern "C" int mi_wordpiece_encode_batch(const mi_wordpiece* w, const char* text, const int64_t* text_offsets, int64_t n,
@@ -177,15 +312,14 @@ extern "C" int mi_wordpiece_encode_batch(const mi_wordpiece* w, const char* text
     const uint64_t hcont0 = fnv_str("##", 2);
     std::atomic<int64_t> next{0};
     auto work = [&]() {
-        std::vector<int32_t> tmp;
-        std::string word;
-        tmp.reserve((size_t)max_len + 64);
+        Scratch sc;
+        sc.tmp.reserve((size_t)max_len + 64);
         for (;;) {
             const int64_t i0 = next.fetch_add(16);
             if (i0 >= n) break;
             const int64_t i1 = std::min(n, i0 + 16);
             for (int64_t i = i0; i < i1; ++i)
-                out_lens[i] = encode_one(w, text + text_offsets[i], (size_t)(text_offsets[i + 1] - text_offsets[i]), max_len, tmp, word,
+                out_lens[i] = encode_one(w, text + text_offsets[i], (size_t)(text_offsets[i + 1] - text_offsets[i]), max_len, sc,
                                          out_ids + i * (int64_t)max_len, hcont0);
         }
     };

@@ -206,16 +206,23 @@ def _is_standard_bert_pipeline(tok) -> Optional[bool]:
 
 
 class NativeWordPiece:
-    """mi_wordpiece_* (rag_amd/csrc/wordpiece.hip): the stock BERT tokenizer pipeline for ASCII texts in C++ on all host
-    cores, straight into the CSR arrays mi_encoder_encode_ragged takes.  Texts with non-ASCII characters keep going
-    through `tokenizers` (accents, CJK, Unicode categories are not restated), so the result is the reference tokenizer's
-    for every input: tests/test_wordpiece.py.  Built only for the stock pipeline, and only if a probe of the vocabulary
-    reproduces `tokenizers` token for token."""
+    """mi_wordpiece_* (rag_amd/csrc/wordpiece.hip): the stock BERT tokenizer pipeline in C++ on all host cores, straight
+    into the CSR arrays mi_encoder_encode_ragged takes.  ASCII text needs nothing else; for the first text with other
+    characters, per-code-point tables (planes 0 and 1) are read off the tokenizer's own normalizer and pre-tokenizer --
+    both work character by character, so the tables ARE their behaviour, whatever Unicode version the library carries --
+    and handed to mi_wordpiece_set_unicode.  Texts the native path declines (a spelled-out special token, a character
+    beyond plane 1, a character of non-zero combining class that survives NFD and could be reordered by it) go through `tokenizers`,
+    so the result is the reference tokenizer's for every input: tests/test_wordpiece.py.  Built only for the stock
+    pipeline, and only if a probe of the vocabulary reproduces `tokenizers` token for token."""
+
+    UNICODE_CODEPOINTS = 0x20000
 
     def __init__(self, tok, max_len: int, n_threads: int = 0):
         lower = _is_standard_bert_pipeline(tok)
         if lower is None:
             raise ValueError("not the stock BERT WordPiece pipeline")
+        if (tok.truncation or {}).get("max_length") != int(max_len) or tok.padding is not None:
+            raise ValueError("the tokenizer must truncate to max_len and not pad (texts the native path declines go through it)")
         vocab = tok.get_vocab()
         size = max(vocab.values()) + 1
         entries = [""] * size
@@ -228,6 +235,7 @@ class NativeWordPiece:
         h = ctypes.c_void_p()
         _capi.check(self._lib.mi_wordpiece_create(blob, len(blob), 1 if lower else 0, ctypes.byref(h)))
         self._h, self.tok, self.max_len, self.n_threads = h, tok, int(max_len), int(n_threads)
+        self.unicode = None                                                      # None: not tried yet; True / False afterwards
         probe = ["", "Hello, World!  a-b_c", "x" * 101 + " " + "y" * 100, "The quick\tbrown\nfox's 12345.678 #tag ##ing [SEP] [MASK]",
                  "tab\x0bsep\x00nul\x7fdel", " ".join(list(vocab)[:: max(1, len(vocab) // 200)][:300])]
         probe = [p for p in probe if p.isascii()]
@@ -249,6 +257,69 @@ class NativeWordPiece:
         except Exception:
             pass
 
+    def _unicode_tables(self):
+        """(cls uint8 [N], map uint32 [N], pool bytes) for mi_wordpiece_set_unicode, read off the reference tokenizer."""
+        import json
+        import unicodedata
+        N = self.UNICODE_CODEPOINTS
+        nz, pt = self.tok.normalizer, self.tok.pre_tokenizer
+        ncfg = json.loads(self.tok.to_str()).get("normalizer") or {}
+        nfd = ncfg.get("strip_accents")
+        nfd = bool(ncfg.get("lowercase", True)) if nfd is None else bool(nfd)       # (BertNormalizer decomposes only to strip accents)
+        cls = [0] * N
+        mp = [0xFFFFFFFF] * N
+        pool = bytearray()
+        outs = set()
+        norm = nz.normalize_str
+        for cp in range(N):
+            if 0xD800 <= cp <= 0xDFFF:
+                cls[cp] = 3
+                continue
+            ch = chr(cp)
+            s = norm(ch)
+            if s != ch:
+                b = s.encode("utf-8")
+                if len(b) > 255 or any(ord(c) >= N for c in s):
+                    cls[cp] = 3                                                  # (maps to itself and declines)
+                    continue
+                mp[cp] = (len(pool) << 8) | len(b)
+                pool += b
+                outs.update(s)
+            else:
+                outs.add(ch)
+        split = pt.pre_tokenize_str
+        for c in outs:
+            kind = {1: 0, 2: 1, 3: 2}.get(len(split("a" + c + "a")), 3)
+            # a character of non-zero combining class that survives NFD could be put in canonical order with its
+            # neighbours by it, which no per-character table can express: such texts stay with the library (and so does a
+            # character this Python does not know but the library kept: its class is anyone's guess)
+            if nfd and (unicodedata.combining(c) or unicodedata.category(c) == "Cn"):
+                kind = 3
+            cls[ord(c)] = max(cls[ord(c)], kind)
+        cls, mp = np.array(cls, dtype=np.uint8), np.array(mp, dtype=np.uint32)
+        return cls, mp, bytes(pool)
+
+    def _enable_unicode(self) -> bool:
+        """Once, at the first non-ASCII text: builds the tables, sets them, and checks a probe against the library."""
+        if self.unicode is not None:
+            return self.unicode
+        self.unicode = False
+        try:
+            cls, mp, pool = self._unicode_tables()
+            _capi.check(self._lib.mi_wordpiece_set_unicode(self._h, cls.size, cls.ctypes.data_as(ctypes.c_void_p),
+                                                           mp.ctypes.data_as(ctypes.c_void_p), pool, len(pool)))
+            self.unicode = True
+            probe = ["caf\u00e9 na\u00efve \u00c5ngstr\u00f6m", "\u201cquoted\u201d \u2014 dash\u2026 \u00a7 1", "\u4e2d\u6587 text \ud55c\uad6d\uc5b4",
+                     "\u0394\u03bf\u03ba\u03b9\u03bc\u03ae \u041f\u0440\u0438\u0432\u0435\u0442", "zero\u200bwidth nb\u00a0sp \ufffd \u0130stanbul", "x\u00e9" * 60 + " " + "\u00e9" * 101]
+            flat, off = self.encode_csr(probe)
+            ref = [e.ids for e in self.tok.encode_batch(probe)]
+            if any(flat[off[i]:off[i + 1]].tolist() != r for i, r in enumerate(ref)):
+                raise ValueError("native WordPiece disagrees with tokenizers on a Unicode probe")
+        except Exception:
+            self.unicode = False
+            self._lib.mi_wordpiece_set_unicode(self._h, 0, None, None, None, 0)
+        return self.unicode
+
     def encode_csr(self, texts: List[str], _self_check: bool = False):
         """texts -> (flat int32 ids, int64 offsets [n + 1]), each text as [CLS] pieces [SEP] cut to max_len."""
         n = len(texts)
@@ -256,14 +327,29 @@ class NativeWordPiece:
         if n == 0:
             return np.zeros(0, dtype=np.int32), offsets
         ascii_mask = np.fromiter((t.isascii() for t in texts), dtype=bool, count=n)
+        if not ascii_mask.all() and not _self_check and self.unicode is not False and self._enable_unicode():
+            enc = [None] * n
+            for i, t in enumerate(texts):
+                try:
+                    enc[i] = t.encode("ascii" if ascii_mask[i] else "utf-8")
+                    ascii_mask[i] = True                                          # (from here on: "goes to the native path")
+                except UnicodeEncodeError:                                       # a lone surrogate: the library's business
+                    pass
+        else:
+            enc = None
         nat = np.flatnonzero(ascii_mask)
         rows = np.empty((n, self.max_len), dtype=np.int32)
         lens = np.zeros(n, dtype=np.int64)
         if nat.size:
             sub = texts if nat.size == n else [texts[i] for i in nat]
-            blob = "".join(sub).encode("ascii")
             toff = np.zeros(nat.size + 1, dtype=np.int64)
-            np.cumsum(np.fromiter((len(t) for t in sub), dtype=np.int64, count=nat.size), out=toff[1:])
+            if enc is None:
+                blob = "".join(sub).encode("ascii")
+                np.cumsum(np.fromiter((len(t) for t in sub), dtype=np.int64, count=nat.size), out=toff[1:])
+            else:
+                sub = [enc[i] for i in nat]
+                blob = b"".join(sub)
+                np.cumsum(np.fromiter((len(b) for b in sub), dtype=np.int64, count=nat.size), out=toff[1:])
             sub_rows = rows if nat.size == n else np.empty((nat.size, self.max_len), dtype=np.int32)
             sub_lens = lens if nat.size == n else np.zeros(nat.size, dtype=np.int64)
             _capi.check(self._lib.mi_wordpiece_encode_batch(self._h, blob, toff.ctypes.data_as(ctypes.c_void_p), nat.size, self.max_len,
@@ -272,7 +358,7 @@ class NativeWordPiece:
             if nat.size != n:
                 rows[nat] = sub_rows
                 lens[nat] = sub_lens
-            ascii_mask = ascii_mask & (lens >= 0)                                # (-1: a spelled-out special token)
+            ascii_mask = ascii_mask & (lens >= 0)                                # (-1: declined, e.g. a spelled-out special token)
         rest = np.flatnonzero(~ascii_mask)
         self.last_native_texts = int(n - rest.size)                             # (the others went through `tokenizers`)
         if rest.size:
