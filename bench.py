@@ -199,7 +199,7 @@ def bench_embed(args, dev, rank, world, barrier):
                                  "tokenize_s": round(tm["tokenize_s"], 3), "gpu_encode_s": round(tm["encode_s"], 3), "total_s": round(el_t, 3),
                                  "tokenizer_texts_per_s": round(tok_rate, 1), "host_threads": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
                                  "bound": "host tokenizer" if tm["tokenize_s"] > tm["encode_s"] else "gpu",
-                                 "tokenizer": "native mi_wordpiece_* (ASCII texts; others through tokenizers)" if nat else "tokenizers",
+                                 "tokenizer": "native mi_wordpiece_* (these texts are ASCII; texts it declines go through tokenizers)" if nat else "tokenizers",
                                  "reference_tokenizer_texts_per_s": round(ref_rate, 1), "tokens_equal_reference_tokenizer": tok_equal,
                                  "path": "List[str] -> WordPiece on all host cores -> CSR -> mi_encoder_encode_ragged -> "
                                          "fp32 rows; slabs of 1,024 texts, tokenising overlapped with the GPU",
