@@ -204,6 +204,33 @@ def bench_embed(args, dev, rank, world, barrier):
                                  "path": "List[str] -> WordPiece on all host cores -> CSR -> mi_encoder_encode_ragged -> "
                                          "fp32 rows; slabs of 1,024 texts, tokenising overlapped with the GPU",
                                  "finite": bool(np.isfinite(Et).all())}
+            # the reranker from STRINGS: 32 queries x 100 passages of ~150 words as (query, passage) pairs through
+            # CrossEncoderReranker.predict (native pair tokenizer on all host cores, slabs overlapped with the GPU)
+            if "rerank" in res:
+                from rag_amd.embeddings import _load_tokenizer
+                from rag_amd.retrievers import CrossEncoderReranker, rerank_pairs_csr
+                rr = CrossEncoderReranker(encoder=enc, tokenizer=_load_tokenizer(mdir, 512), max_length=512)
+                rr.slab_pairs = 800
+                qs = synthetic_texts(32, 12, cfg.vocab_size, seed=8)
+                ps = synthetic_texts(3200, 150, cfg.vocab_size, seed=9)
+                pairs = [(qs[i // 100], ps[i]) for i in range(3200)]
+                rr.predict(pairs[:200])
+                t0 = time.perf_counter()
+                sc = rr.predict(pairs)
+                el_rt = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                f_n, t_n, o_n = rr._pairs_csr(pairs[:800])
+                nat_rate = 800 / (time.perf_counter() - t0)
+                t0 = time.perf_counter()
+                f_r, t_r, o_r = rerank_pairs_csr(pairs[:800], rr.tokenizer, 512)
+                lib_rate = 800 / (time.perf_counter() - t0)
+                res["rerank"]["from_texts"] = {
+                    "value": round(3200 / el_rt, 1), "unit": "pairs/s", "mean_tokens_per_pair": round(float(np.diff(o_n).mean()), 1),
+                    "tokenizer": "native mi_wordpiece_encode_pairs" if rr.native_tokenizer is not None else "tokenizers",
+                    "tokenizer_pairs_per_s": round(nat_rate, 1), "reference_tokenizer_pairs_per_s": round(lib_rate, 1),
+                    "tokens_equal_reference_tokenizer": bool(np.array_equal(f_n, f_r) and np.array_equal(t_n, t_r) and np.array_equal(o_n, o_r)),
+                    "finite": bool(np.isfinite(sc).all()),
+                    "path": "List[(str, str)] -> pair WordPiece on all host cores -> CSR -> mi_encoder_classify_ragged -> logits; slabs of 800 pairs"}
             del emb
         finally:
             shutil.rmtree(mdir, ignore_errors=True)

@@ -313,7 +313,13 @@ int  mi_encoder_last_time(const mi_encoder* enc, float* out_ms);
  * into: 0xFFFFFFFF = itself, else (offset into pool << 8) | number of bytes of UTF-8 there (0 bytes = the character is
  * dropped).  cls[cp] says what an OUTPUT character is to BertPreTokenizer: 0 word character, 1 space, 2 punctuation (a
  * word of its own), 3 decline (the whole text is handed back with -1).  The tables are copied; n_codepoints = 0 removes
- * them.  Not to be called while encode_batch runs on the same tokenizer. */
+ * them.  Not to be called while encode_batch / encode_pairs run on the same tokenizer.
+ * encode_pairs: the cross-encoder's input (no counterpart in advanced_rag.py, which has no reranker: README.md:27 and
+ * requirements.txt:24 name one; the framing is `tokenizers`' for a BERT pair): row i = [CLS] a_i [SEP] b_i [SEP], out_types
+ * the segment ids (0 up to and including the first [SEP], 1 after), cut to max_len (>= 3) by the library's default
+ * "longest_first" rule: the longer side gives way first, both get half of the room when both are long.  out_ids and
+ * out_types hold n rows of max_len; out_lens[i] = -1 when either side is declined as above.  Equal neighbouring a_i
+ * (one query against many passages) are tokenised once. */
 typedef struct mi_wordpiece mi_wordpiece;
 int  mi_wordpiece_create(const char* vocab, int64_t vocab_bytes, int lowercase, mi_wordpiece** out);
 int  mi_wordpiece_set_unicode(mi_wordpiece* wp, int64_t n_codepoints, const uint8_t* cls, const uint32_t* map,
@@ -321,6 +327,9 @@ int  mi_wordpiece_set_unicode(mi_wordpiece* wp, int64_t n_codepoints, const uint
 void mi_wordpiece_destroy(mi_wordpiece* wp);
 int  mi_wordpiece_encode_batch(const mi_wordpiece* wp, const char* text, const int64_t* text_offsets, int64_t n,
                                int max_len, int n_threads, int32_t* out_ids, int64_t* out_lens);
+int  mi_wordpiece_encode_pairs(const mi_wordpiece* wp, const char* text_a, const int64_t* offsets_a, const char* text_b,
+                               const int64_t* offsets_b, int64_t n, int max_len, int n_threads, int32_t* out_ids,
+                               int32_t* out_types, int64_t* out_lens);
 
 #ifdef __cplusplus
 }

@@ -111,6 +111,7 @@ SYMBOLS = {
     "mi_wordpiece_set_unicode": (_i32, [_vp, _i64, _vp, _vp, ctypes.c_char_p, _i64]),
     "mi_wordpiece_destroy": (None, [_vp]),
     "mi_wordpiece_encode_batch": (_i32, [_vp, ctypes.c_char_p, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "mi_wordpiece_encode_pairs": (_i32, [_vp, ctypes.c_char_p, _vp, ctypes.c_char_p, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -133,18 +133,16 @@ inline uint32_t utf8_at(const unsigned char* t, size_t i, size_t n, uint32_t* le
     return cp;
 }
 
-struct Scratch { std::vector<int32_t> tmp; std::string word; std::vector<uint32_t> ends; };
+struct Scratch { std::vector<int32_t> tmp, tmp_a; std::string word; std::vector<uint32_t> ends; bool a_ok = false; };
 
-// UTF-8 text through the tables; -1 = declined
-int64_t encode_one_u(const mi_wordpiece* w, const char* t, size_t n, int max_len, Scratch& sc, int32_t* out, uint64_t hcont0)
+// UTF-8 text through the tables: its pieces (at least `budget` of them if it has that many) into tmp; false = declined
+bool pieces_u(const mi_wordpiece* w, const char* t, size_t n, size_t budget, Scratch& sc, std::vector<int32_t>& tmp, uint64_t hcont0)
 {
     const unsigned char* u = (const unsigned char*)t;
     const size_t ncp = w->umap.size();
-    std::vector<int32_t>& tmp = sc.tmp;
     std::string& word = sc.word;
     std::vector<uint32_t>& ends = sc.ends;
     tmp.clear(); word.clear(); ends.clear();
-    const size_t budget = max_len >= 2 ? (size_t)max_len - 2 : 0;
     auto flush = [&]() { if (!ends.empty()) { word_pieces_u(w, word.data(), ends.data(), ends.size(), tmp, hcont0); word.clear(); ends.clear(); } };
     // one OUTPUT character (bytes p[0:len), code point cp) into the splitter; false = decline
     auto feed = [&](uint32_t cp, const char* p, uint32_t len) -> bool {
@@ -159,34 +157,29 @@ int64_t encode_one_u(const mi_wordpiece* w, const char* t, size_t n, int max_len
     for (size_t i = 0; i < n && tmp.size() < budget;) {
         uint32_t len;
         const uint32_t cp = utf8_at(u, i, n, &len);
-        if (len == 0 || cp >= ncp) return -1;
+        if (len == 0 || cp >= ncp) return false;
         const uint32_t m = w->umap[cp];
-        if (m == 0xFFFFFFFFu) { if (!feed(cp, t + i, len)) return -1; }
+        if (m == 0xFFFFFFFFu) { if (!feed(cp, t + i, len)) return false; }
         else {
             const char* p = w->upool.data() + (m >> 8);
             const size_t pn = m & 0xFF;
             for (size_t k = 0; k < pn;) {                        // (validated when the tables were set)
                 uint32_t l2;
                 const uint32_t c2 = utf8_at((const unsigned char*)p, k, pn, &l2);
-                if (!feed(c2, p + k, l2)) return -1;
+                if (!feed(c2, p + k, l2)) return false;
                 k += l2;
             }
         }
         i += len;
     }
     if (tmp.size() < budget) flush();
-    const size_t m = std::min(tmp.size(), budget);
-    int64_t k = 0;
-    if (max_len >= 1) out[k++] = w->cls;
-    for (size_t i = 0; i < m; ++i) out[k++] = tmp[i];
-    if (max_len >= 2) out[k++] = w->sep;
-    return k;
+    return true;
 }
 
-// -1: declined (see the header of this file); else the number of ids written to out (<= max_len)
-int64_t encode_one(const mi_wordpiece* w, const char* t, size_t n, int max_len, Scratch& sc, int32_t* out, uint64_t hcont0)
+// the pieces of one text (no [CLS] / [SEP]) into tmp, stopping once `budget` of them exist (pieces past a cut are never
+// needed); false: declined (see the header of this file)
+bool pieces(const mi_wordpiece* w, const char* t, size_t n, size_t budget, Scratch& sc, std::vector<int32_t>& tmp, uint64_t hcont0)
 {
-    std::vector<int32_t>& tmp = sc.tmp;
     std::string& word = sc.word;
     bool high = false;
     for (size_t i = 0; i < n; ++i) {
@@ -195,15 +188,14 @@ int64_t encode_one(const mi_wordpiece* w, const char* t, size_t n, int max_len, 
         if (c == '[') {                                        // "[SEP]", "[MASK]", ... in the text: the reference matches its special
             size_t j = i + 1;                                  // tokens in the raw string before anything else -- leave the text to it
             while (j < n && t[j] >= 'A' && t[j] <= 'Z') ++j;
-            if (j > i + 1 && j < n && t[j] == ']') return -1;
+            if (j > i + 1 && j < n && t[j] == ']') return false;
         }
     }
-    if (high) return w->umap.empty() ? -1 : encode_one_u(w, t, n, max_len, sc, out, hcont0);
+    if (high) return !w->umap.empty() && pieces_u(w, t, n, budget, sc, tmp, hcont0);
     tmp.clear();
     word.clear();
-    const size_t budget = max_len >= 2 ? (size_t)max_len - 2 : 0;
     auto flush = [&]() { if (!word.empty()) { word_pieces(w, word.data(), word.size(), tmp, hcont0); word.clear(); } };
-    for (size_t i = 0; i < n && tmp.size() < budget; ++i) {      // (pieces past the budget are cut anyway: stop early)
+    for (size_t i = 0; i < n && tmp.size() < budget; ++i) {
         unsigned char c = (unsigned char)t[i];
         if (c == ' ' || c == '\t' || c == '\n' || c == '\r') { flush(); continue; }
         if (c < 32 || c == 127) continue;                      // control characters vanish (they do not separate words)
@@ -212,12 +204,75 @@ int64_t encode_one(const mi_wordpiece* w, const char* t, size_t n, int max_len, 
         word.push_back((char)c);
     }
     if (tmp.size() < budget) flush();
-    const size_t m = std::min(tmp.size(), budget);
+    return true;
+}
+
+// [CLS] pieces[: max_len - 2] [SEP] into out; -1: declined, else the number of ids written (<= max_len)
+int64_t encode_one(const mi_wordpiece* w, const char* t, size_t n, int max_len, Scratch& sc, int32_t* out, uint64_t hcont0)
+{
+    const size_t budget = max_len >= 2 ? (size_t)max_len - 2 : 0;
+    if (!pieces(w, t, n, budget, sc, sc.tmp, hcont0)) return -1;
+    const size_t m = std::min(sc.tmp.size(), budget);
     int64_t k = 0;
     if (max_len >= 1) out[k++] = w->cls;
-    for (size_t i = 0; i < m; ++i) out[k++] = tmp[i];
+    for (size_t i = 0; i < m; ++i) out[k++] = sc.tmp[i];
     if (max_len >= 2) out[k++] = w->sep;
     return k;
+}
+
+// [CLS] A [SEP] B [SEP] with segment ids 0 0 0 1 1, cut to max_len the way `tokenizers` cuts a pair ("longest_first",
+// truncation.rs): with room = max_len - 3 and n1 <= n2 the two piece counts, nothing is cut if they fit; else the longer
+// one alone gives way while the shorter fits in half the room, else both are cut to room / 2 (the longer keeps the odd one).
+// The rule needs the TRUE counts of both sides (which of two over-long sides is "longer" decides who gets the odd piece),
+// so neither side stops early.  -1: one side was declined.
+int64_t encode_pair(const mi_wordpiece* w, const char* ta, size_t na, const char* tb, size_t nb, int max_len, Scratch& sc,
+                    bool reuse_a, int32_t* out, int32_t* types, uint64_t hcont0)
+{
+    const size_t all = (size_t)-1;
+    if (!reuse_a) sc.a_ok = pieces(w, ta, na, all, sc, sc.tmp_a, hcont0);
+    if (!sc.a_ok) return -1;
+    if (!pieces(w, tb, nb, all, sc, sc.tmp, hcont0)) return -1;
+    size_t n1 = sc.tmp_a.size(), n2 = sc.tmp.size();
+    const size_t room = (size_t)max_len - 3;
+    if (n1 + n2 > room) {
+        const bool swap = n1 > n2;
+        if (swap) std::swap(n1, n2);
+        n2 = n1 > room ? n1 : std::max(n1, room - n1);
+        if (n1 + n2 > room) { n1 = room / 2; n2 = n1 + room % 2; }
+        if (swap) std::swap(n1, n2);
+        n1 = std::min(n1, sc.tmp_a.size());
+        n2 = std::min(n2, sc.tmp.size());
+    }
+    int64_t k = 0;
+    out[k] = w->cls; types[k++] = 0;
+    for (size_t i = 0; i < n1; ++i) { out[k] = sc.tmp_a[i]; types[k++] = 0; }
+    out[k] = w->sep; types[k++] = 0;
+    for (size_t i = 0; i < n2; ++i) { out[k] = sc.tmp[i]; types[k++] = 1; }
+    out[k] = w->sep; types[k++] = 1;
+    return k;
+}
+
+int pool_threads(int n_threads, int64_t n)
+{
+    int T = n_threads;
+    if (T <= 0) {
+        const char* e = getenv("OMP_NUM_THREADS");
+        T = e ? atoi(e) : 0;
+        if (T <= 0) { T = (int)std::thread::hardware_concurrency(); if (T > 16) T = 16; }
+    }
+    if (T < 1) T = 1;
+    if ((int64_t)T > (n + 15) / 16) T = (int)((n + 15) / 16);
+    return T;
+}
+
+template <class F> void run_pool(int T, F&& work)
+{
+    if (T == 1) { work(); return; }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)T - 1);
+    for (int t = 1; t < T; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
 }
 }  // namespace
 
@@ -301,17 +356,10 @@ extern "C" int mi_wordpiece_encode_batch(const mi_wordpiece* w, const char* text
     MI_REQUIRE(n == 0 || text || text_offsets[n] == text_offsets[0], "mi_wordpiece_encode_batch: NULL text");
     for (int64_t i = 0; i < n; ++i) MI_REQUIRE(text_offsets[i + 1] >= text_offsets[i], "mi_wordpiece_encode_batch: offsets must not decrease");
     if (n == 0) return MI_OK;
-    int T = n_threads;
-    if (T <= 0) {
-        const char* e = getenv("OMP_NUM_THREADS");
-        T = e ? atoi(e) : 0;
-        if (T <= 0) { T = (int)std::thread::hardware_concurrency(); if (T > 16) T = 16; }
-    }
-    if (T < 1) T = 1;
-    if ((int64_t)T > (n + 15) / 16) T = (int)((n + 15) / 16);
+    const int T = pool_threads(n_threads, n);
     const uint64_t hcont0 = fnv_str("##", 2);
     std::atomic<int64_t> next{0};
-    auto work = [&]() {
+    run_pool(T, [&]() {
         Scratch sc;
         sc.tmp.reserve((size_t)max_len + 64);
         for (;;) {
@@ -322,12 +370,38 @@ extern "C" int mi_wordpiece_encode_batch(const mi_wordpiece* w, const char* text
                 out_lens[i] = encode_one(w, text + text_offsets[i], (size_t)(text_offsets[i + 1] - text_offsets[i]), max_len, sc,
                                          out_ids + i * (int64_t)max_len, hcont0);
         }
-    };
-    if (T == 1) { work(); return MI_OK; }
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)T - 1);
-    for (int t = 1; t < T; ++t) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+    });
+    return MI_OK;
+}
+
+extern "C" int mi_wordpiece_encode_pairs(const mi_wordpiece* w, const char* text_a, const int64_t* offsets_a, const char* text_b,
+                                         const int64_t* offsets_b, int64_t n, int max_len, int n_threads, int32_t* out_ids,
+                                         int32_t* out_types, int64_t* out_lens)
+{
+    MI_REQUIRE(w && (n == 0 || (offsets_a && offsets_b && out_ids && out_types && out_lens)), "mi_wordpiece_encode_pairs: NULL argument");
+    MI_REQUIRE(n >= 0 && max_len >= 3 && max_len <= 65536, "mi_wordpiece_encode_pairs: n / max_len out of range (max_len >= 3)");
+    MI_REQUIRE(n == 0 || ((text_a || offsets_a[n] == offsets_a[0]) && (text_b || offsets_b[n] == offsets_b[0])), "mi_wordpiece_encode_pairs: NULL text");
+    for (int64_t i = 0; i < n; ++i)
+        MI_REQUIRE(offsets_a[i + 1] >= offsets_a[i] && offsets_b[i + 1] >= offsets_b[i], "mi_wordpiece_encode_pairs: offsets must not decrease");
+    if (n == 0) return MI_OK;
+    const int T = pool_threads(n_threads, n);
+    const uint64_t hcont0 = fnv_str("##", 2);
+    std::atomic<int64_t> next{0};
+    run_pool(T, [&]() {
+        Scratch sc;
+        for (;;) {
+            const int64_t i0 = next.fetch_add(16);
+            if (i0 >= n) break;
+            const int64_t i1 = std::min(n, i0 + 16);
+            for (int64_t i = i0; i < i1; ++i) {
+                const char* ta = text_a + offsets_a[i];
+                const size_t na = (size_t)(offsets_a[i + 1] - offsets_a[i]);
+                // one query against many passages: the first text of a pair is tokenised once per run of equal texts
+                const bool same = i > i0 && na == (size_t)(offsets_a[i] - offsets_a[i - 1]) && memcmp(ta, text_a + offsets_a[i - 1], na) == 0;
+                out_lens[i] = encode_pair(w, ta, na, text_b + offsets_b[i], (size_t)(offsets_b[i + 1] - offsets_b[i]), max_len, sc, same,
+                                          out_ids + i * (int64_t)max_len, out_types + i * (int64_t)max_len, hcont0);
+            }
+        }
+    });
     return MI_OK;
 }

@@ -221,8 +221,10 @@ class NativeWordPiece:
         lower = _is_standard_bert_pipeline(tok)
         if lower is None:
             raise ValueError("not the stock BERT WordPiece pipeline")
-        if (tok.truncation or {}).get("max_length") != int(max_len) or tok.padding is not None:
-            raise ValueError("the tokenizer must truncate to max_len and not pad (texts the native path declines go through it)")
+        tr = tok.truncation or {}
+        if (tr.get("max_length") != int(max_len) or tr.get("direction", "right") != "right" or tok.padding is not None
+                or tr.get("strategy", "longest_first") not in ("longest_first", "only_first")):
+            raise ValueError("the tokenizer must truncate to max_len (on the right) and not pad (texts the native path declines go through it)")
         vocab = tok.get_vocab()
         size = max(vocab.values()) + 1
         entries = [""] * size
@@ -319,6 +321,68 @@ class NativeWordPiece:
             self.unicode = False
             self._lib.mi_wordpiece_set_unicode(self._h, 0, None, None, None, 0)
         return self.unicode
+
+    def pairs_supported(self) -> bool:
+        """True when (a, b) pairs are framed [CLS] a [SEP] b [SEP] with segment ids 0 0 0 1 1 and cut "longest_first" with
+        no stride: what mi_wordpiece_encode_pairs restates."""
+        import json
+        try:
+            pp = json.loads(self.tok.to_str()).get("post_processor") or {}
+            tr = self.tok.truncation or {}
+            if tr.get("strategy", "longest_first") != "longest_first" or tr.get("stride", 0) != 0 or self.max_len < 3:
+                return False
+            if pp.get("type") == "BertProcessing":
+                return True
+            pair = [(list(x.keys())[0], list(x.values())[0].get("id"), list(x.values())[0].get("type_id")) for x in pp.get("pair", [])]
+            return pair == [("SpecialToken", "[CLS]", 0), ("Sequence", "A", 0), ("SpecialToken", "[SEP]", 0),
+                            ("Sequence", "B", 1), ("SpecialToken", "[SEP]", 1)]
+        except Exception:
+            return False
+
+    def encode_pairs_csr(self, pairs):
+        """(a, b) string pairs -> (flat int32 ids, flat int32 segment ids, int64 offsets [n + 1]): the cross-encoder's
+        input, each pair as the tokenizer's own encode(a, b) gives it.  Pairs the native path declines go through it."""
+        n = len(pairs)
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        if n == 0:
+            return np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32), offsets
+        ok = np.ones(n, dtype=bool)
+        if not all(a.isascii() and b.isascii() for a, b in pairs) and self.unicode is not False:
+            self._enable_unicode()
+        codec = "utf-8" if self.unicode else "ascii"
+        ea, eb = [b""] * n, [b""] * n
+        last_a, last_ea = None, b""
+        for i, (a, b) in enumerate(pairs):
+            try:
+                if a is not last_a:
+                    last_a, last_ea = a, a.encode(codec)
+                ea[i], eb[i] = last_ea, b.encode(codec)
+            except UnicodeEncodeError:                                           # non-ASCII without tables, or a lone surrogate
+                ok[i] = False
+                last_a = None
+        offa = np.zeros(n + 1, dtype=np.int64)
+        offb = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.fromiter((len(x) for x in ea), dtype=np.int64, count=n), out=offa[1:])
+        np.cumsum(np.fromiter((len(x) for x in eb), dtype=np.int64, count=n), out=offb[1:])
+        rows = np.empty((n, self.max_len), dtype=np.int32)
+        types = np.empty((n, self.max_len), dtype=np.int32)
+        lens = np.zeros(n, dtype=np.int64)
+        p = ctypes.c_void_p
+        _capi.check(self._lib.mi_wordpiece_encode_pairs(self._h, b"".join(ea), offa.ctypes.data_as(p), b"".join(eb), offb.ctypes.data_as(p), n,
+                                                        self.max_len, self.n_threads, rows.ctypes.data_as(p), types.ctypes.data_as(p),
+                                                        lens.ctypes.data_as(p)))
+        ok &= lens >= 0
+        rest = np.flatnonzero(~ok)
+        self.last_native_texts = int(n - rest.size)
+        for i in rest:
+            e = self.tok.encode(pairs[i][0], pairs[i][1])
+            m = len(e.ids)
+            rows[i, :m] = e.ids
+            types[i, :m] = e.type_ids
+            lens[i] = m
+        np.cumsum(lens, out=offsets[1:])
+        keep = np.arange(self.max_len)[None, :] < lens[:, None]
+        return np.ascontiguousarray(rows[keep], dtype=np.int32), np.ascontiguousarray(types[keep], dtype=np.int32), offsets
 
     def encode_csr(self, texts: List[str], _self_check: bool = False):
         """texts -> (flat int32 ids, int64 offsets [n + 1]), each text as [CLS] pieces [SEP] cut to max_len."""

@@ -14,6 +14,7 @@ this image, so parity is pinned by hand-computed cases in tests/test_retrievers.
 from __future__ import annotations
 
 import math
+import os
 from typing import Any, Callable, Dict, Iterable, List, Optional, Sequence
 
 from .documents import Document
@@ -195,8 +196,9 @@ def rerank_pairs_csr(pairs: Sequence[Sequence[str]], tokenizer: Any, max_length:
     tokenizer without truncation configured is cut here, keeping the closing token too (_cut_pair)."""
     import numpy as np
     ids, types, offsets = [], [], [0]
-    for q, passage in pairs:
-        e = tokenizer.encode(q, passage)
+    batch = getattr(tokenizer, "encode_batch", None)                 # (`tokenizers`: all pairs in one call, on all cores)
+    encs = batch([(q, passage) for q, passage in pairs]) if batch else (tokenizer.encode(q, passage) for q, passage in pairs)
+    for e in encs:
         ei, et = _cut_pair(e.ids, e.type_ids, max_length)
         ids.extend(ei)
         types.extend(et)
@@ -225,6 +227,22 @@ class CrossEncoderReranker:
             tokenizer = _load_tokenizer(model_name, max_length)
         self.encoder, self.tokenizer, self.max_length, self.activation = encoder, tokenizer, int(max_length), activation
         self.score_label = score_label                  # column of a multi-label head that rank() orders by
+        # the stock BERT pair pipeline runs natively on all host cores (mi_wordpiece_encode_pairs), token for token with
+        # `tokenizers`; anything else, and every pair the native path declines, stays with the library
+        self.native_tokenizer = None
+        self.slab_pairs = 16384
+        if os.environ.get("MI_NATIVE_TOKENIZER", "1") != "0" and hasattr(encoder, "classify_ragged"):
+            try:
+                from .embeddings import NativeWordPiece
+                nat = NativeWordPiece(tokenizer, self.max_length)
+                self.native_tokenizer = nat if nat.pairs_supported() else None
+            except Exception:
+                self.native_tokenizer = None
+
+    def _pairs_csr(self, pairs):
+        if self.native_tokenizer is not None:
+            return self.native_tokenizer.encode_pairs_csr(pairs)
+        return rerank_pairs_csr(pairs, self.tokenizer, self.max_length)
 
     def predict(self, pairs: Sequence[Sequence[str]]):
         import numpy as np
@@ -233,8 +251,20 @@ class CrossEncoderReranker:
         # pairs of different lengths go down as one flat token array: the library packs its passes without padding
         # (mi_encoder_classify_ragged).  An encoder without that entry point (a test double) gets the padded batch.
         if hasattr(self.encoder, "classify_ragged"):
-            flat_ids, flat_types, offsets = rerank_pairs_csr(pairs, self.tokenizer, self.max_length)
-            logits = self.encoder.classify_ragged(flat_ids, flat_types, offsets)
+            # slabs: a worker thread tokenises slab i + 1 (the native call and `tokenizers` both release the GIL) while
+            # the GPU scores slab i
+            from concurrent.futures import ThreadPoolExecutor
+            pairs = pairs if isinstance(pairs, list) else list(pairs)
+            cuts = list(range(0, len(pairs), self.slab_pairs)) + [len(pairs)]
+            out = []
+            with ThreadPoolExecutor(max_workers=1) as ex:
+                nxt = ex.submit(self._pairs_csr, pairs[cuts[0]:cuts[1]])
+                for j in range(1, len(cuts)):
+                    flat_ids, flat_types, offsets = nxt.result()
+                    if j + 1 < len(cuts):
+                        nxt = ex.submit(self._pairs_csr, pairs[cuts[j]:cuts[j + 1]])
+                    out.append(self.encoder.classify_ragged(flat_ids, flat_types, offsets))
+            logits = out[0] if len(out) == 1 else np.concatenate(out)
         else:
             docs = [Document(page_content=p[1]) for p in pairs]
             queries = {p[0] for p in pairs}

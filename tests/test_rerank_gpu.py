@@ -173,6 +173,13 @@ def test_top100_feeds_the_rerank_batch(tmp_path, oracle_mod):
     query = "the red cat sat on the mat"
     scores = rr.predict([(query, dd.page_content) for dd in docs])
     assert scores.shape == (k,)
+    # the pairs went through the native pair tokenizer; the library's tokens give the same scores, and so do small slabs
+    assert rr.native_tokenizer is not None and rr.native_tokenizer.last_native_texts == k
+    nat, rr.native_tokenizer = rr.native_tokenizer, None
+    assert np.array_equal(rr.predict([(query, dd.page_content) for dd in docs]), scores)
+    rr.native_tokenizer, rr.slab_pairs = nat, 32
+    assert np.array_equal(rr.predict([(query, dd.page_content) for dd in docs]), scores)
+    rr.slab_pairs = 16384
     ids, types, mask = rerank_pairs(query, docs, rr.tokenizer, 64)
     assert types.max() == 1 and ids.shape[0] == k
     cfg, blob, head = load_local_dir(str(tmp_path / "x"), normalize=False, with_head=True)

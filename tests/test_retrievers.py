@@ -218,3 +218,36 @@ def test_rank_with_a_multi_label_head_needs_a_column():
     by1 = CrossEncoderReranker(encoder=_Enc(), tokenizer=_Tok(), max_length=64, score_label=1).rank("q", docs, top_n=2)
     assert [d.page_content for d in by0] == ["a b c d e", "a b c", "a"]
     assert [d.page_content for d in by1] == ["a", "a b c"]
+
+
+def test_reranker_slab_pipeline_with_native_pairs(tmp_path):
+    """CrossEncoderReranker.predict over several slabs: the native pair tokenizer and `tokenizers` hand the encoder the
+    same flat arrays (a test double that hashes them stands in for the GPU), in the pairs' order."""
+    from rag_amd.embeddings import _load_tokenizer
+    from rag_amd.retrievers import CrossEncoderReranker
+    _write_model_dir(str(tmp_path / "m"), hidden=32, layers=1, heads=2, inter=64, head_labels=1)
+    tok = _load_tokenizer(str(tmp_path / "m"), 24)
+
+    class _Enc:
+        calls = 0
+
+        def classify_ragged(self, flat_ids, flat_types, offsets):
+            _Enc.calls += 1
+            w = np.arange(1, flat_ids.size + 1, dtype=np.int64) % 7 + 1
+            c = np.concatenate([[0], np.cumsum(flat_ids.astype(np.int64) * w * (1 + flat_types))])
+            return (c[offsets[1:]] - c[offsets[:-1]]).astype(np.float32)[:, None] - np.diff(offsets)[:, None] * 3.0
+
+    rng = np.random.default_rng(5)
+    words = ["the", "cat", "sat", "on", "mat", "dogs", "chase", "red", "Flat!", "index-row", "zzz"]
+    pairs = [(" ".join(rng.choice(words, size=int(rng.integers(0, 12)))), " ".join(rng.choice(words, size=int(rng.integers(0, 40)))))
+             for _ in range(300)]
+    rr = CrossEncoderReranker(encoder=_Enc(), tokenizer=tok, max_length=24)
+    assert rr.native_tokenizer is not None
+    rr.slab_pairs = 64
+    got = rr.predict(pairs)
+    assert got.shape == (300,) and _Enc.calls == 5 and rr.native_tokenizer.last_native_texts == 300 - 64 * 4
+    # slab by slab through the library: the double's score depends on the position inside a slab, so keep the slabs
+    nat, rr.native_tokenizer = rr.native_tokenizer, None
+    assert np.array_equal(rr.predict(pairs), got)
+    rr.native_tokenizer = nat
+    assert rr.predict([]).shape == (0,)

@@ -281,3 +281,47 @@ def test_unicode_tables_are_validated_and_bad_utf8_is_declined(tmp_path):
         assert encode("é".encode())[0] == -1
     finally:
         lib.mi_wordpiece_destroy(h)
+
+
+# ---- (query, passage) pairs for the cross-encoder (mi_wordpiece_encode_pairs) ----
+
+@pytest.mark.parametrize("max_len", [3, 4, 5, 16, 17, 64])
+def test_pairs_equal_tokenizers(tmp_path, max_len):
+    """[CLS] a [SEP] b [SEP], segment ids, and the library's "longest_first" cut (which side gives way, who keeps the odd
+    piece) against tokenizers' own encode(a, b), for even and odd room and both orders of long / short."""
+    from tokenizers import BertWordPieceTokenizer
+    from rag_amd.embeddings import NativeWordPiece
+    p = os.path.join(str(tmp_path), "vocab.txt")
+    with open(p, "w", encoding="utf-8") as f:
+        f.write("\n".join(_unicode_vocab()) + "\n")
+    tok = BertWordPieceTokenizer(p, lowercase=True)._tokenizer
+    tok.no_padding()
+    tok.enable_truncation(max_length=max_len)
+    nat = NativeWordPiece(tok, max_len)
+    assert nat.pairs_supported()
+    rnd = random.Random(max_len)
+    words = STEMS + ["café", "привет", "—", "retrievers", "x" * 101]
+
+    def txt(k):
+        return " ".join(rnd.choice(words) for _ in range(k))
+
+    pairs = [(txt(rnd.randint(0, max_len)), txt(rnd.randint(0, 2 * max_len))) for _ in range(1500)]
+    pairs += [(txt(rnd.randint(0, 2 * max_len)), txt(rnd.randint(0, max_len))) for _ in range(1500)]
+    q = txt(5)
+    pairs += [(q, txt(rnd.randint(0, 30))) for _ in range(100)]                    # one query, many passages
+    pairs += [("", ""), ("a", ""), ("", "a"), ("[SEP] x", "y"), ("x", "[MASK]"), ("\U00020000", "y"), ("y", "\U00020000 z")]
+    flat, types, off = nat.encode_pairs_csr(pairs)
+    assert flat.dtype == np.int32 and types.dtype == np.int32 and off[-1] == flat.size == types.size
+    assert nat.last_native_texts == len(pairs) - 4                                 # the last four were handed back
+    for i, (a, b) in enumerate(pairs):
+        e = tok.encode(a, b)
+        assert flat[off[i]:off[i + 1]].tolist() == e.ids and types[off[i]:off[i + 1]].tolist() == e.type_ids, (max_len, a, b)
+    assert int(np.diff(off).max()) == max_len
+    f1, t1, o1 = NativeWordPiece(tok, max_len, n_threads=1).encode_pairs_csr(pairs)
+    assert np.array_equal(f1, flat) and np.array_equal(t1, types) and np.array_equal(o1, off)
+    # a tokenizer that cuts pairs another way is not restated
+    tok.enable_truncation(max_length=max_len, strategy="only_first")
+    assert not NativeWordPiece(tok, max_len).pairs_supported()
+    tok.enable_truncation(max_length=max_len, strategy="only_second")
+    with pytest.raises(ValueError):
+        NativeWordPiece(tok, max_len)
