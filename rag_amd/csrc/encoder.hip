@@ -36,6 +36,7 @@
 #include <vector>
 #include "kernels.h"
 #include "encoder_ffn3.h"
+#include "encoder_qkv_attn.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1707,6 +1708,7 @@ static int scratch_for_device(int device, void** out)
 
 struct LayerW {
     uint16_t *Wqkv, *Wo, *Wi, *Wd;                 // bf16 [out][in]
+    uint16_t* Wqkv_p = nullptr;                    // Wqkv per head in MFMA operand order (encoder_qkv_attn.hip)
     uint16_t *Wi_p = nullptr;                      // [I / 32][12][32][32] swizzled LDS image of Wi blocks (ffn2_kernel)
     uint16_t *Wo_p = nullptr, *Wd_p = nullptr;     // the same, [in / 32][out][32]: a 32-k stage of gemm_ln_kernel is one contiguous block
     float *bqkv, *bo, *bi, *bd, *g1, *b1, *g2, *b2; // fp32
@@ -1828,7 +1830,7 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
     { const int src = scratch_for_device(device, &e->scratch_dev); if (src != MI_OK) return fail(src); }
     ENC_HIP(hipMalloc((void**)&e->blob, (size_t)want * sizeof(float)));
     ENC_HIP(hipMemcpyAsync(e->blob, blob_host, (size_t)want * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    const int64_t per_layer_w = (int64_t)4 * H * H + 2 * (int64_t)I * H + ((int64_t)H * H + 2 * (int64_t)H * I);   // + packed Wo, Wd, Wi
+    const int64_t per_layer_w = (int64_t)4 * H * H + 2 * (int64_t)I * H + ((int64_t)H * H + 2 * (int64_t)H * I) + (int64_t)3 * H * H;   // + packed Wo, Wd, Wi, Wqkv
     ENC_HIP(hipMalloc((void**)&e->wbf, (size_t)(per_layer_w * cfg->num_hidden_layers) * sizeof(uint16_t)));
     for (auto& n : e->ln) { ENC_HIP(hipEventCreate(&n.ev0)); ENC_HIP(hipEventCreate(&n.ev1)); }
     ENC_HIP(hipStreamCreateWithFlags(&e->st2, hipStreamNonBlocking));
@@ -1869,6 +1871,7 @@ extern "C" int mi_encoder_create(mi_ctx* ctx, const mi_bert_config* cfg, const f
         lw.Wo_p = w; cvt_pack32_kernel<<<1024, 256, 0, e->stream>>>(Wo, w, H, H); w += (int64_t)H * H;
         lw.Wd_p = w; cvt_pack32_kernel<<<1024, 256, 0, e->stream>>>(Wd, w, H, I); w += (int64_t)H * I;
         lw.Wi_p = w; if (H == 384) cvt_pack_w1_kernel<<<1024, 256, 0, e->stream>>>(Wi, w, I); w += (int64_t)H * I;
+        lw.Wqkv_p = w; { const int prc = mi_qkv_attn_pack(e->stream, lw.Wqkv, w, H, NH); if (prc != MI_OK) return fail(prc); } w += (int64_t)3 * H * H;
         // fused qkv bias: bq|bk|bv are not contiguous in the blob -> a small packed copy
         lw.bqkv = nullptr;
         hipError_t me = hipMalloc((void**)&lw.bqkv, (size_t)3 * H * sizeof(float));
@@ -2162,9 +2165,21 @@ static int encode_pass_locked(mi_encoder* e, int64_t B, int L, const int32_t* id
     if (!capturing) MI_HIP(hipEventRecord(ln.ev0, st));
     if (H <= 512) embed_ln_kernel<1><<<tok_grid, 256, 0, st>>>(ids, types, pos_ids, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
     else embed_ln_kernel<2><<<tok_grid, 256, 0, st>>>(ids, types, pos_ids, c.type_vocab_size, T, L, H, c.vocab_size, e->word, e->pos, e->type0, e->eg, e->eb, c.layer_norm_eps, h);
+    // bulk passes of sequences up to 256 tokens: QKV projection and attention in one kernel (encoder_qkv_attn.hip), the QKV
+    // tensor never goes to memory.  MI_QKV_FUSED=0: the two kernels; read per call (A/B, tests)
+    // The fused kernel streams a head's weight slice once per sequence whatever its length: passes of short sequences stay
+    // with the two kernels (mean length below MI_QKV_FUSED_MIN_MEAN tokens).
+    int64_t fused_min_mean = 128;
+    if (const char* s = getenv("MI_QKV_FUSED_MIN_MEAN")) fused_min_mean = atoll(s);
+    const bool qkv_fused = bulk && L <= MI_QKV_ATTN_MAX_L && B <= 65535 && T >= B * fused_min_mean &&
+                           !(getenv("MI_QKV_FUSED") && atoi(getenv("MI_QKV_FUSED")) == 0);
     for (const LayerW& lw : e->layers) {
-        const bool qkv_blocked = launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H, true);
-        attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, seq_start, ctx, L, Lp, H, qkv_blocked ? 1 : 0, fused_ln ? 1 : 0);
+        if (qkv_fused) {
+            MI_TRY(mi_launch_qkv_attn(st, h, lw.Wqkv_p, lw.bqkv, mask, seq_start, ctx, B, L, H, NH, fused_ln ? 1 : 0));
+        } else {
+            const bool qkv_blocked = launch_gemm<EPI_BIAS>(st, h, lw.Wqkv, lw.bqkv, nullptr, qkv, (int)T, 3 * H, H, true);
+            attn_kernel<<<dim3(NH, (unsigned)B, (L + 255) / 256), 256, attn_smem, st>>>(qkv, mask, seq_start, ctx, L, Lp, H, qkv_blocked ? 1 : 0, fused_ln ? 1 : 0);
+        }
         if (ffn3 && lw.w3) {
             MI_TRY(mi_launch_ffn3(st, ctx, h, lw.w3, lw.p3, c.layer_norm_eps, h, (int)T));
             continue;

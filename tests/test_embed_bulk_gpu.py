@@ -293,3 +293,70 @@ def test_two_lanes_equal_one_lane_and_stay_ordered(oracle_mod, monkeypatch):
         monkeypatch.setenv("MI_ENC_LANES", lanes)
         R[lanes] = enc.encode_ragged(flat, off, max_len=L)
     assert np.array_equal(R["2"], R["1"])
+
+
+def test_fused_qkv_attention_equals_the_two_kernels_and_the_oracle(oracle_mod, monkeypatch):
+    """qkv_attn_kernel (encoder_qkv_attn.hip: QKV projection + attention in one kernel, bulk passes of sequences up to 256
+    tokens) against the two kernels it replaces (MI_QKV_FUSED=0, read per call) and against the oracle: sequence lengths on
+    every edge of its tiling (1, 31..33, 63..65, 127..129, 255, 256), a batch that is no multiple of 8 (the XCD-aware grid is
+    rounded up), packed sequences and padded ones with a key mask -- masked keys in the middle, and a fully masked row, which
+    must still come out uniform over its padded length as the reference's finfo.min arithmetic gives it.  Longer sequences
+    (257 ..) keep taking the two kernels."""
+    from rag_amd._capi import BertConfig
+    from rag_amd.embeddings import Encoder
+    from rag_amd.encoder_weights import random_blob
+    vals = (1000, 384, 2, 12, 1536, 512, 2, 1e-12, 1)
+    cfg, ocfg = BertConfig(*vals), oracle_mod.BertConfig(*vals)
+    blob = random_blob(cfg, seed=31, init_range=0.05)
+    enc = Encoder(cfg, blob)
+    monkeypatch.setenv("MI_ENC_LATENCY_TOKENS", "0")        # every pass takes the bulk kernels
+    monkeypatch.setenv("MI_QKV_FUSED_MIN_MEAN", "0")        # ... and the fused kernel whatever the mean length
+    rng = np.random.default_rng(9)
+    edge = [1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 191, 192, 193, 255, 256]
+    lens = np.array(edge + list(rng.integers(1, 257, size=70 - len(edge))))          # 70 sequences: not a multiple of 8
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat = rng.integers(0, 1000, size=int(off[-1])).astype(np.int32)
+
+    def both(fn):
+        out = {}
+        for m in ("1", "0"):
+            monkeypatch.setenv("MI_QKV_FUSED", m)
+            out[m] = fn()
+        return out["1"], out["0"]
+
+    # packed sequences, one pass per length group and all in one
+    for max_batch in (0, 9):
+        Ef, Eu = both(lambda: enc.encode_ragged(flat, off, max_len=256, max_batch=max_batch))
+        assert np.all(_cos_err(Ef, Eu) < 2e-5), float(_cos_err(Ef, Eu).max())
+        rows = list(range(len(edge))) + [40, 69]
+        want = _oracle_rows(oracle_mod, ocfg, blob, flat, off, rows)
+        assert np.all(_cos_err(Ef[rows], want) < TOL)
+    # padded with a key mask
+    B, L = 21, 200
+    ids = rng.integers(0, 1000, size=(B, L)).astype(np.int32)
+    mask = np.ones((B, L), dtype=np.int32)
+    mask[1, 150:] = 0
+    mask[2, 40:90] = 0                                        # a hole in the middle
+    mask[3, :] = 0
+    mask[3, 0] = 1                                            # one key
+    mask[4, 1:] = 0
+    mask[5, :] = 0                                            # nothing to attend to, nothing to pool: the zero vector either way
+    Ef, Eu = both(lambda: enc.encode_ids(ids, mask))
+    live = [i for i in range(B) if i != 5]
+    assert np.all(_cos_err(Ef[live], Eu[live]) < 2e-5)
+    assert np.array_equal(Ef[5], Eu[5])
+    want = oracle_mod.encode(ocfg, blob, ids[:6], mask[:6])
+    assert np.all(_cos_err(Ef[:5], want[:5]) < TOL)
+    # the hidden states of a fully masked sequence (attention uniform over its padded length) through the classifier head,
+    # which reads token 0 whatever the mask says
+    from rag_amd.encoder_weights import random_head
+    enc.set_head(*random_head(cfg, num_labels=2, seed=3, init_range=0.1))
+    types = np.zeros_like(ids)
+    Lf, Lu = both(lambda: enc.classify(ids[:8], types[:8], mask[:8]))
+    assert np.allclose(Lf, Lu, rtol=0, atol=2e-2), float(np.abs(Lf - Lu).max())
+    # beyond 256 tokens the fused kernel steps aside: same bits with the switch either way
+    lens2 = np.array([300, 257, 512, 64])
+    off2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int64)
+    flat2 = rng.integers(0, 1000, size=int(off2[-1])).astype(np.int32)
+    Ef, Eu = both(lambda: enc.encode_ragged(flat2, off2, max_len=512))
+    assert np.array_equal(Ef, Eu)

@@ -10,7 +10,7 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-corre
 if [ "$FILE" == "encoder_ffn3" ]; then F="$F -mllvm -amdgpu-spill-vgpr-to-agpr=0"; fi   # as rag_amd/_build.py FILE_FLAGS
 /opt/rocm/bin/hipcc $F $2 -c rag_amd/csrc/$FILE.hip -o tools/_ab/$1_$FILE.o
 OBJS=""
-for o in capi multi ingest search_exact search_mfma encoder encoder_ffn3 wordpiece; do
+for o in capi multi ingest search_exact search_mfma encoder encoder_ffn3 encoder_qkv_attn wordpiece; do
   if [ "$o" == "$FILE" ]; then OBJS="$OBJS tools/_ab/$1_$FILE.o"; else OBJS="$OBJS build/obj/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_ab/$1.so $OBJS
