@@ -36,6 +36,7 @@ while time.time() < t_end:
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     flat = rng.integers(0, 3000, size=int(offsets[-1])).astype(np.int32)
     os.environ["MI_ENC_LATENCY_TOKENS"] = str(rng.choice([0, 12288, 1 << 30]))     # always bulk / default hand-over / never bulk
+    os.environ["MI_QKV_FUSED_MIN_MEAN"] = str(rng.choice([0, 0, 128]))          # qkv_attn_kernel for every bulk pass up to 256 tokens / default
     max_batch = int(rng.choice([0, 0, 5, 33]))
     E = enc.encode_ragged(flat, offsets, max_len=max_len, max_batch=max_batch)
     # oracle: padded batch of the truncated sequences

@@ -46,6 +46,7 @@ while time.time() < t_end:
     flat_ids = np.concatenate([ids[b, :lens[b]] for b in range(n)])
     flat_types = np.concatenate([types[b, :lens[b]] for b in range(n)])
     os.environ["MI_ENC_LATENCY_TOKENS"] = str(rng.choice([0, 12288, 1 << 30]))
+    os.environ["MI_QKV_FUSED_MIN_MEAN"] = str(rng.choice([0, 0, 128]))          # qkv_attn_kernel for every bulk pass up to 256 tokens / default
     got = enc.classify_ragged(flat_ids, flat_types, off, max_batch=int(rng.choice([0, 0, 3, 10])))
     want = oracle.classify(ocfg, blob, head, ids, types, mask)
     err = float(np.abs(got - want).max()) / tol
