@@ -551,23 +551,28 @@ class MI355Embeddings:
         tok_s = enc_s = 0.0
         tokens = 0
 
-        def tok(i0):
+        # the first slab is short (the GPU has nothing to do until it is tokenised), the others `slab_texts` long
+        cuts = [0, min(S, 512)]
+        while cuts[-1] < n:
+            cuts.append(min(n, cuts[-1] + S))
+
+        def tok(j):
             t0 = time.perf_counter()
-            r = self._tokenize_csr(texts[i0:i0 + S])
+            r = self._tokenize_csr(texts[cuts[j]:cuts[j + 1]])
             return r, time.perf_counter() - t0
         with ThreadPoolExecutor(max_workers=1) as ex:
             nxt = ex.submit(tok, 0)
-            for i0 in range(0, n, S):
+            for j in range(len(cuts) - 1):
                 (flat, offsets), dt = nxt.result()
                 tok_s += dt
-                if i0 + S < n:
-                    nxt = ex.submit(tok, i0 + S)
+                if j + 2 < len(cuts):
+                    nxt = ex.submit(tok, j + 1)
                 t0 = time.perf_counter()
-                out[i0:i0 + S] = self._encode_csr(flat, offsets)
+                out[cuts[j]:cuts[j + 1]] = self._encode_csr(flat, offsets)
                 enc_s += time.perf_counter() - t0
                 tokens += int(offsets[-1])
         self.last_timing = {"tokenize_s": tok_s, "encode_s": enc_s, "total_s": time.perf_counter() - t_all,
-                            "slabs": (n + S - 1) // S, "tokens": tokens}
+                            "slabs": len(cuts) - 1, "tokens": tokens}
         return out
 
     def embed_documents(self, texts: List[str]) -> List[List[float]]:
